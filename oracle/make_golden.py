@@ -191,6 +191,10 @@ def gen_model_vectors():
     for tag, factory, names, psets in model_cases():
         m = factory()
         qq = qk if tag == "kholodenko" else q
+        # model.calc needs a data object with f.binnedData for shape (scatteringmodel.py:89);
+        # use ITS q everywhere (unit round trip nm^-1 -> SI is not exact to the last bit)
+        d = sasdata(qq * 1e-9, np.ones_like(qq), 0.01 * np.ones_like(qq))
+        qq = np.array(d.q, dtype=float)
         ds = QOnly(qq)
         ff = []
         for pv in psets:
@@ -200,8 +204,6 @@ def gen_model_vectors():
         out[tag + "_q"] = qq
         out[tag + "_pset"] = np.array(psets, dtype=float)
         out[tag + "_ff"] = np.array(ff)
-        # G2: model.calc needs a data object with f.binnedData for shape (scatteringmodel.py:89)
-        d = sasdata(qq * 1e-9, np.ones_like(qq), 0.01 * np.ones_like(qq))
         md = m.calc(d, np.array(psets, dtype=float), cexp)
         out[tag + "_cumInt"] = np.array(md.cumInt)
         out[tag + "_vset"] = np.array(md.vset)
