@@ -1,0 +1,173 @@
+/* mcsas_hip.h — C ABI of the MI355X-native McSAS Monte-Carlo core (libmcsas_hip.so).
+ *
+ * This is the drop-in boundary.  The reference has no FFI; the path it replaces is
+ * the pure-Python call chain
+ *     McSAS.analyse()                         src/mcsas/mcsas/mcsas.py:191-285
+ *       -> McSAS.mcFit()                      src/mcsas/mcsas/mcsas.py:287-439
+ *            -> ScatteringModel.calc()        src/mcsas/bases/model/scatteringmodel.py:79-109
+ *            -> BackgroundScalingFit.calc()   src/mcsas/mcsas/backgroundscalingfit.py:112-139
+ *            -> ScatteringModel.generateParameters()  src/mcsas/bases/model/scatteringmodel.py:117-127
+ * Every entry point below names the reference interface it stands in for.  Plain pointers and
+ * sizes only; all arrays are caller-owned host memory, double = IEEE binary64, C order.
+ * All functions return 0 on success or a negative MCSAS_E* code and never throw; the message of
+ * the last failure on the calling thread is available from mcsas_hip_last_error().
+ * One in-flight call per plan (mirrors the reference's non-reentrant model objects).
+ */
+#ifndef MCSAS_HIP_H
+#define MCSAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCSAS_ABI_VERSION 1
+#define MCSAS_MAX_ACTIVE 4   /* active (fitted) parameters per contribution: columns of rset */
+#define MCSAS_MAX_PARAMS 8   /* full parameter vector of a model */
+
+/* model_id: which ScatteringModel.formfactor/volume/absVolume/surface set is evaluated.
+ * Parameter vector order = the reference's `parameters` tuple of that class. */
+enum {
+    MCSAS_MODEL_SPHERE = 0,      /* models/sphere.py:12-63            (radius, sld) */
+    MCSAS_MODEL_CYL_ISO = 1,     /* models/cylindersisotropic.py:17-101 (radius, useAspect, length, aspect, intDiv, sld) */
+    MCSAS_MODEL_ELL_CS = 2,      /* models/ellipsoidalcoreshell.py:14-97 (a, b, t, eta_c, eta_s, eta_sol, intDiv) */
+    MCSAS_MODEL_KHOLODENKO = 3,  /* models/kholodenko.py:51-94         (radius, lenKuhn, lenContour) */
+    MCSAS_MODEL_COUNT = 4
+};
+
+/* gen_kind: NumberGenerator subclass of an active parameter (bases/algorithm/numbergenerator.py) */
+enum {
+    MCSAS_GEN_UNIFORM = 0,  /* RandomUniform       :28-31   u */
+    MCSAS_GEN_EXP1 = 1,     /* RandomExponential   :168-175 (10^u - 1)/10 */
+    MCSAS_GEN_EXP2 = 2,     /* RandomExponential2  :181-184 (10^(2u) - 1)/100 */
+    MCSAS_GEN_EXP3 = 3      /* RandomExponential3  :186-189 (10^(3u) - 1)/1000 */
+};
+
+enum {
+    MCSAS_OK = 0,
+    MCSAS_EINVAL = -1,      /* bad argument / unsupported size */
+    MCSAS_ENODEV = -2,      /* no usable HIP device */
+    MCSAS_EHIP = -3,        /* HIP runtime error (see mcsas_hip_last_error) */
+    MCSAS_ENOMEM = -4,
+    MCSAS_ESTREAM = -5      /* replay stream shorter than the draws a chain consumed */
+};
+
+/* Everything McSAS.analyse() reads from self.data, self.model and the algorithm settings. */
+typedef struct mcsas_problem {
+    uint32_t struct_size;        /* sizeof(mcsas_problem), ABI check */
+    int32_t  model_id;           /* MCSAS_MODEL_* */
+
+    /* data: SASData.q, data.f.binnedData, data.f.binnedDataU (dataobj/sasdata.py:51-55,
+     * backgroundscalingfit.py:113-117; sigma == 0 is treated as 1 like the reference). SI units. */
+    int32_t  nq;
+    const double *q;
+    const double *intensity;
+    const double *sigma;
+
+    /* model: values of ALL parameters (inactive ones are used as they are) + the active set */
+    double   params[MCSAS_MAX_PARAMS];
+    int32_t  n_active;                           /* model.activeParamCount() */
+    int32_t  active_index[MCSAS_MAX_ACTIVE];     /* ascending indices into params[] (activeParams() order) */
+    double   gen_lo[MCSAS_MAX_ACTIVE];           /* activeRange ∩ valueRange (utils/parameter.py:715-728, */
+    double   gen_hi[MCSAS_MAX_ACTIVE];           /*   bases/algorithm/parameter.py:66-84) */
+    int32_t  gen_kind[MCSAS_MAX_ACTIVE];         /* MCSAS_GEN_* */
+    double   clip_lo[MCSAS_MAX_ACTIVE];          /* valueRange: Parameter.setValue clips into it */
+    double   clip_hi[MCSAS_MAX_ACTIVE];          /*   (bases/algorithm/parameter.py:405-414,489-495) */
+    double   start_value[MCSAS_MAX_ACTIVE];      /* startFromMinimum fill value (mcsas.py:310-315) */
+
+    /* algorithm settings (mcsas/mcsasparameters.json) */
+    int32_t  n_contrib;          /* numContribs */
+    int32_t  n_reps;             /* numReps handled by THIS call (a shard when multi-GPU) */
+    int64_t  max_iter;           /* maxIterations */
+    double   comp_exp;           /* compensationExponent */
+    double   conv_crit;          /* convergenceCriterion */
+    int32_t  max_retries;        /* maxRetries: up to max_retries+1 attempts per rep (mcsas.py:220-246) */
+    int32_t  find_background;    /* findBackground */
+    int32_t  positive_background;
+    int32_t  start_from_minimum;
+
+    /* random numbers.  Free-running: Philox4x32-10 keyed by `seed`, one independent stream per
+     * chain id (rep_offset + local rep).  Replay: replay_stream != NULL supplies, per rep, the
+     * raw uniforms numpy.random.uniform would have returned, consumed in the reference's order
+     * (N draws per active parameter at chain start, then n_active per step; retries continue). */
+    uint64_t seed;
+    int32_t  rep_offset;         /* global index of this shard's first rep */
+    int32_t  reserved0;
+    const double *replay_stream; /* [n_reps][replay_len] or NULL */
+    int64_t  replay_len;
+
+    /* cooperative stop (McSAS.stop, mcsas.py:357): polled by the host while the kernel runs and
+     * forwarded to the device; may be NULL */
+    const volatile int32_t *stop;
+
+    /* execution */
+    int32_t  device;             /* HIP device ordinal, -1 = current device */
+    int32_t  waves_per_chain;    /* 0 = auto; 1 = one wavefront per chain; >1 = workgroup per chain */
+    int32_t  cache_intensities;  /* -1 auto, 0 re-evaluate `old` every step like mcsas.py:362, 1 keep rows in HBM */
+    int32_t  reserved1;
+} mcsas_problem;
+
+/* What mcFit returns per repetition (mcsas.py:428-439) gathered the way analyse() stores it
+ * (mcsas.py:203-210,233-251).  Caller allocates every non-NULL array. */
+typedef struct mcsas_result {
+    uint32_t struct_size;
+    uint32_t reserved;
+    double  *contribs;     /* [n_contrib][n_active][n_reps]  == contributions, mcsas.py:203-205 */
+    double  *fit;          /* [nq][n_reps]                   == contribMeasVal[0], mcsas.py:210 */
+    double  *chisq;        /* [n_reps] final reduced chi-squared (conval) */
+    double  *scaling;      /* [n_reps] details['scaling'] */
+    double  *background;   /* [n_reps] details['background'] */
+    int64_t *num_iter;     /* [n_reps] details['numIterations'] of the last attempt */
+    int64_t *num_moves;    /* [n_reps] details['numMoves'] */
+    int32_t *attempts;     /* [n_reps] mcFit calls made for this rep */
+    int32_t *converged;    /* [n_reps] chisq <= conv_crit */
+    double  *seconds;      /* [n_reps] device wall time of the chain, all attempts */
+    int64_t *draws;        /* [n_reps] uniforms consumed (replay bookkeeping); may be NULL */
+} mcsas_result;
+
+/* ---- one-shot: replaces McSAS.analyse()'s repetition loop (mcsas.py:214-262) ---------------- */
+int mcsas_hip_analyse(const mcsas_problem *problem, mcsas_result *result);
+
+/* ---- resident plan: same work split so that inputs/workspaces live in HBM across runs ------- */
+typedef struct mcsas_plan mcsas_plan;
+int  mcsas_hip_plan_create(const mcsas_problem *problem, mcsas_plan **plan);
+/* enqueue all chains on `hip_stream` (a hipStream_t, NULL = default stream); asynchronous */
+int  mcsas_hip_plan_launch(mcsas_plan *plan, void *hip_stream);
+/* wait for the launch (forwarding problem->stop meanwhile) and copy results out */
+int  mcsas_hip_plan_fetch(mcsas_plan *plan, mcsas_result *result);
+/* device time of the last launch measured with HIP events on its stream, milliseconds */
+int  mcsas_hip_plan_last_ms(mcsas_plan *plan, double *ms);
+/* total MC steps executed by the last launch (sum of iterations over chains and attempts) */
+int  mcsas_hip_plan_total_steps(mcsas_plan *plan, int64_t *steps);
+/* change seed / rep_offset between launches without re-uploading anything else */
+int  mcsas_hip_plan_reseed(mcsas_plan *plan, uint64_t seed, int32_t rep_offset);
+void mcsas_hip_plan_destroy(mcsas_plan *plan);
+
+/* ---- ScatteringModel.calc(data, pset, compensationExponent) (scatteringmodel.py:79-109) ------
+ * Uses problem->{model_id, params, n_active, active_index, clip_*, nq, q, comp_exp, device}.
+ * pset[n][n_active] -> cum_int[nq] (rows summed in order), vset/wset/sset[n], optional
+ * rows[n][nq] (each contribution's F²·w, i.e. SASModel.calcIntensity()[0], sasmodel.py:46-79). */
+int mcsas_hip_model_calc(const mcsas_problem *problem, const double *pset, int32_t n,
+                         double *cum_int, double *vset, double *wset, double *sset, double *rows);
+
+/* ---- BackgroundScalingFit.calc (backgroundscalingfit.py:112-139), closed-form minimiser ------
+ * out[4] = { sc[0] (scaling), sc[1] (background), conval (reduced chi²), aGoFs } */
+int mcsas_hip_bgfit(int32_t nq, const double *intensity, const double *sigma, const double *model_int,
+                    int32_t find_background, int32_t positive_background, int32_t num_params,
+                    int32_t device, double out[4]);
+
+/* ---- McSAS.histogram()'s per-contribution visibility limits (mcsas.py:575-594) --------------
+ * For each rep: min over q of sigma·vf_c / (A·I_c(q)) where I_c != 0.  contribs in the
+ * (n_contrib, n_active, n_reps) layout of mcsas_result, vol_frac/min_req_vol [n_contrib][n_reps]. */
+int mcsas_hip_observability(const mcsas_problem *problem, const double *contribs,
+                            const double *scaling, const double *vol_frac, double *min_req_vol);
+
+int         mcsas_hip_device_count(void);
+int         mcsas_hip_abi_version(void);
+const char *mcsas_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCSAS_HIP_H */

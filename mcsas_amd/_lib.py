@@ -1,0 +1,121 @@
+"""ctypes binding of libmcsas_hip.so (include/mcsas_hip.h).
+
+There is no CPU fallback: if the shared library is missing or cannot be loaded this module raises
+and every product entry point fails loudly.  Build it with `python __graft_entry__.py build` (or
+`make -C mcsas_amd/csrc`); hipcc cross-compiles for gfx950 without a GPU present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+MAX_ACTIVE = 4
+MAX_PARAMS = 8
+ABI_VERSION = 1
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmcsas_hip.so")
+
+# every symbol include/mcsas_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = (
+    "mcsas_hip_analyse", "mcsas_hip_plan_create", "mcsas_hip_plan_launch", "mcsas_hip_plan_fetch",
+    "mcsas_hip_plan_last_ms", "mcsas_hip_plan_total_steps", "mcsas_hip_plan_reseed",
+    "mcsas_hip_plan_destroy", "mcsas_hip_model_calc", "mcsas_hip_bgfit", "mcsas_hip_observability",
+    "mcsas_hip_device_count", "mcsas_hip_abi_version", "mcsas_hip_last_error",
+)
+
+_dp = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("model_id", C.c_int32),
+        ("nq", C.c_int32),
+        ("q", _dp), ("intensity", _dp), ("sigma", _dp),
+        ("params", C.c_double * MAX_PARAMS),
+        ("n_active", C.c_int32),
+        ("active_index", C.c_int32 * MAX_ACTIVE),
+        ("gen_lo", C.c_double * MAX_ACTIVE), ("gen_hi", C.c_double * MAX_ACTIVE),
+        ("gen_kind", C.c_int32 * MAX_ACTIVE),
+        ("clip_lo", C.c_double * MAX_ACTIVE), ("clip_hi", C.c_double * MAX_ACTIVE),
+        ("start_value", C.c_double * MAX_ACTIVE),
+        ("n_contrib", C.c_int32), ("n_reps", C.c_int32),
+        ("max_iter", C.c_int64),
+        ("comp_exp", C.c_double), ("conv_crit", C.c_double),
+        ("max_retries", C.c_int32), ("find_background", C.c_int32),
+        ("positive_background", C.c_int32), ("start_from_minimum", C.c_int32),
+        ("seed", C.c_uint64),
+        ("rep_offset", C.c_int32), ("reserved0", C.c_int32),
+        ("replay_stream", _dp), ("replay_len", C.c_int64),
+        ("stop", _i32p),
+        ("device", C.c_int32), ("waves_per_chain", C.c_int32),
+        ("cache_intensities", C.c_int32), ("reserved1", C.c_int32),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("reserved", C.c_uint32),
+        ("contribs", _dp), ("fit", _dp), ("chisq", _dp), ("scaling", _dp), ("background", _dp),
+        ("num_iter", _i64p), ("num_moves", _i64p), ("attempts", _i32p), ("converged", _i32p),
+        ("seconds", _dp), ("draws", _i64p),
+    ]
+
+
+class McSASHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libmcsas_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises if it is not built (no fallback by design)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "mcsas_amd: %s not found. The HIP library is the product path and has no CPU fallback; "
+            "build it with `python __graft_entry__.py build`." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise ImportError("libmcsas_hip.so lacks symbols: %s" % ", ".join(missing))
+    lib.mcsas_hip_abi_version.restype = C.c_int
+    if lib.mcsas_hip_abi_version() != ABI_VERSION:
+        raise ImportError("libmcsas_hip.so ABI %d, binding expects %d" % (lib.mcsas_hip_abi_version(), ABI_VERSION))
+    lib.mcsas_hip_last_error.restype = C.c_char_p
+    lib.mcsas_hip_device_count.restype = C.c_int
+    lib.mcsas_hip_analyse.argtypes = [C.POINTER(Problem), C.POINTER(Result)]
+    lib.mcsas_hip_plan_create.argtypes = [C.POINTER(Problem), C.POINTER(C.c_void_p)]
+    lib.mcsas_hip_plan_launch.argtypes = [C.c_void_p, C.c_void_p]
+    lib.mcsas_hip_plan_fetch.argtypes = [C.c_void_p, C.POINTER(Result)]
+    lib.mcsas_hip_plan_last_ms.argtypes = [C.c_void_p, _dp]
+    lib.mcsas_hip_plan_total_steps.argtypes = [C.c_void_p, _i64p]
+    lib.mcsas_hip_plan_reseed.argtypes = [C.c_void_p, C.c_uint64, C.c_int32]
+    lib.mcsas_hip_plan_destroy.argtypes = [C.c_void_p]
+    lib.mcsas_hip_plan_destroy.restype = None
+    lib.mcsas_hip_model_calc.argtypes = [C.POINTER(Problem), _dp, C.c_int32, _dp, _dp, _dp, _dp, _dp]
+    lib.mcsas_hip_bgfit.argtypes = [C.c_int32, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]
+    lib.mcsas_hip_observability.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, _dp]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise McSASHipError(rc, load().mcsas_hip_last_error().decode("utf-8", "replace"))
+
+
+def as_dp(a):
+    return a.ctypes.data_as(_dp)
+
+
+def f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))

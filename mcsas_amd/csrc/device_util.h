@@ -1,0 +1,89 @@
+// device_util.h — wave64 primitives for the McSAS chain kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcsas {
+
+constexpr int WAVE = 64;
+
+// ---- cross-lane (DPP) -----------------------------------------------------------------------
+// DPP controls (CDNA ISA): quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141,
+// row_bcast15 0x142, row_bcast31 0x143.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // old = 0 so rows masked off contribute +0.0
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes; every lane gets the total (wave-uniform, lives in SGPRs).
+// xor-1, xor-2 inside quads, half-mirror (8), mirror (16), then the two row broadcasts.
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_f64<0xB1>(v);           // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);           // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);          // row_half_mirror
+    v += dpp_f64<0x140>(v);          // row_mirror  -> each 16-lane row holds its total
+    v += dpp_f64<0x142, 0xA>(v);     // row_bcast15 into rows 1,3
+    v += dpp_f64<0x143, 0xC>(v);     // row_bcast31 into rows 2,3 -> row 3 holds the total
+    return readlane_f64(v, 63);
+}
+
+// three sums at once: the chains are independent so the DPP latencies interleave
+__device__ __forceinline__ void wave_sum3(double &a, double &b, double &c) {
+    a += dpp_f64<0xB1>(a); b += dpp_f64<0xB1>(b); c += dpp_f64<0xB1>(c);
+    a += dpp_f64<0x4E>(a); b += dpp_f64<0x4E>(b); c += dpp_f64<0x4E>(c);
+    a += dpp_f64<0x141>(a); b += dpp_f64<0x141>(b); c += dpp_f64<0x141>(c);
+    a += dpp_f64<0x140>(a); b += dpp_f64<0x140>(b); c += dpp_f64<0x140>(c);
+    a += dpp_f64<0x142, 0xA>(a); b += dpp_f64<0x142, 0xA>(b); c += dpp_f64<0x142, 0xA>(c);
+    a += dpp_f64<0x143, 0xC>(a); b += dpp_f64<0x143, 0xC>(b); c += dpp_f64<0x143, 0xC>(c);
+    a = readlane_f64(a, 63); b = readlane_f64(b, 63); c = readlane_f64(c, 63);
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+    v = fmin(v, __shfl_xor(v, 1)); v = fmin(v, __shfl_xor(v, 2));
+    v = fmin(v, __shfl_xor(v, 4)); v = fmin(v, __shfl_xor(v, 8));
+    v = fmin(v, __shfl_xor(v, 16)); v = fmin(v, __shfl_xor(v, 32));
+    return v;
+}
+
+// ---- Philox4x32-10 (Salmon et al., SC'11) ----------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1;
+        c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// draw `idx` of chain `chain`: counter (idx>>1, chain, 0), even idx -> words 0,1, odd -> 2,3;
+// 53-bit double ((a>>5)*2^26 + (b>>6)) / 2^53, the construction numpy's legacy generator uses.
+__device__ __forceinline__ double philox_uniform(uint64_t seed, uint32_t chain, uint64_t idx) {
+    uint64_t blk = idx >> 1;
+    uint32_t c[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), chain, 0u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t a = (idx & 1) ? c[2] : c[0], b = (idx & 1) ? c[3] : c[1];
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+
+// NumberGenerator.get transforms (numbergenerator.py:28-31,168-191)
+__device__ __forceinline__ double gen_transform(int kind, double u) {
+    if (kind == 0) return u;
+    double up = (double)kind;
+    double rs = pow(10.0, 0.0 + (up - 0.0) * u);
+    double den = (kind == 1) ? 10.0 : (kind == 2 ? 100.0 : 1000.0);
+    return (rs - 1.0) / den;
+}
+
+}  // namespace mcsas

@@ -1,0 +1,545 @@
+// mcsas_hip.hip — libmcsas_hip.so: C ABI (include/mcsas_hip.h) over the gfx950 chain kernels.
+// Built only for MI355X (gfx950); there is no CPU path in here.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mcsas_hip.h"
+#include "chain_wave.h"
+#include "chain_wg.h"
+
+using namespace mcsas;
+
+// ------------------------------------------------------------------------------ error plumbing
+static thread_local std::string g_err;
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? MCSAS_ENOMEM : MCSAS_EHIP, "%s: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+    } while (0)
+
+// ------------------------------------------------------------------------------ small kernels
+// rows[n][q] = SASModel.calcIntensity()[0] for contribution n (sasmodel.py:46-79); one wave per row
+template <int M>
+__global__ __launch_bounds__(64) void model_rows_kernel(ModelArgs m, int nq, const double *q, const double *pset,
+                                                        int n, double *rows, double *vset, double *wset, double *sset) {
+    extern __shared__ double tab[];
+    Contrib<M>::fill_table(m, tab, threadIdx.x, WAVE);
+    __syncthreads();
+    const int i = blockIdx.x;
+    double row[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+    for (int p = 0; p < m.n_active; ++p) row[p] = pset[(size_t)i * m.n_active + p];
+    Contrib<M> c;
+    c.prepare(m, row);
+    if (threadIdx.x == 0) { vset[i] = c.v; wset[i] = c.w; sset[i] = c.s; }
+    for (int k = threadIdx.x; k < nq; k += WAVE) rows[(size_t)i * nq + k] = c.intensity(q[k], tab);
+}
+
+// cumInt += it, contribution by contribution (scatteringmodel.py:101): thread per q, fixed order
+__global__ void rows_cumsum_kernel(int nq, int n, const double *rows, double *cum) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nq) return;
+    double s = 0.;
+    for (int i = 0; i < n; ++i) s += rows[(size_t)i * nq + k];
+    cum[k] = s;
+}
+
+// BackgroundScalingFit.calc with the closed-form minimiser; one wave
+__global__ __launch_bounds__(64) void bgfit_kernel(int nq, const double *I, const double *sigma, const double *C,
+                                                   int find_bg, int pos_bg, int num_params, double *out) {
+    const int lane = threadIdx.x;
+    double sw = 0, si = 0, sii = 0, sc = 0, scc = 0, sic = 0, ss2 = 0;
+    for (int k = lane; k < nq; k += WAVE) {
+        double e = sigma[k] == 0.0 ? 1.0 : sigma[k];       // backgroundscalingfit.py:117
+        double w = 1.0 / (e * e);
+        sw += w; si += w * I[k]; sii += w * I[k] * I[k];
+        sc += w * C[k]; scc += w * C[k] * C[k]; sic += w * I[k] * C[k]; ss2 += e * e;
+    }
+    wave_sum3(sw, si, sii); wave_sum3(sc, scc, sic); ss2 = wave_sum(ss2);
+    ChainArgs a{};
+    a.Sw = sw; a.SI = si; a.SII = sii; a.nq = nq; a.find_bg = find_bg; a.pos_bg = pos_bg;
+    FitResult f = solve_fit(a, sc, scc, sic);
+    double rs = 0, r2 = 0;
+    for (int k = lane; k < nq; k += WAVE) {
+        double e = sigma[k] == 0.0 ? 1.0 : sigma[k];
+        double r = I[k] - (C[k] * f.A + f.b);
+        rs += (r / e) * (r / e); r2 += r * r;
+    }
+    rs = wave_sum(rs); r2 = wave_sum(r2);
+    if (lane == 0) {
+        out[0] = f.A; out[1] = f.b; out[2] = rs / nq;
+        out[3] = r2 / ss2 * ((double)nq / (double)(nq - num_params));   // aGoFsAlpha :79-84, :136-138
+    }
+}
+
+// min over q of sigma*vf / (A*I_c(q)), I_c != 0 (mcsas.py:582-590); one wave per (contribution, rep)
+template <int M>
+__global__ __launch_bounds__(64) void observability_kernel(ModelArgs m, int nq, const double *q, const double *sigma,
+                                                           int N, int R, const double *contribs, const double *scaling,
+                                                           const double *vol_frac, double *min_req) {
+    extern __shared__ double tab[];
+    Contrib<M>::fill_table(m, tab, threadIdx.x, WAVE);
+    __syncthreads();
+    const int c = blockIdx.x, r = blockIdx.y, P = m.n_active;
+    double row[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+    for (int p = 0; p < P; ++p) row[p] = contribs[((size_t)c * P + p) * R + r];
+    Contrib<M> cc;
+    cc.prepare(m, row);
+    const double vf = vol_frac[(size_t)c * R + r], A = scaling[r];
+    double best = INFINITY;
+    for (int k = threadIdx.x; k < nq; k += WAVE) {
+        double scaled = A * cc.intensity(q[k], tab);
+        if (scaled != 0.) best = fmin(best, (sigma[k] * vf) / scaled);
+    }
+    best = wave_min(best);
+    if (threadIdx.x == 0) min_req[(size_t)c * R + r] = best;
+}
+
+// ------------------------------------------------------------------------------ host helpers
+static int model_int_div(const mcsas_problem *p) {
+    switch (p->model_id) {
+        case MCSAS_MODEL_CYL_ISO: return (int)p->params[4];
+        case MCSAS_MODEL_ELL_CS: return (int)p->params[6];
+        default: return 1;
+    }
+}
+
+static int fill_model_args(const mcsas_problem *p, ModelArgs *m) {
+    if (p->model_id < 0 || p->model_id >= MCSAS_MODEL_COUNT) return fail(MCSAS_EINVAL, "unknown model_id %d", p->model_id);
+    if (p->model_id == MCSAS_MODEL_KHOLODENKO) return fail(MCSAS_EINVAL, "Kholodenko model: kernel not built yet");
+    if (p->n_active < 1 || p->n_active > MCSAS_MAX_ACTIVE) return fail(MCSAS_EINVAL, "n_active %d out of range", p->n_active);
+    memset(m, 0, sizeof *m);
+    m->model_id = p->model_id; m->n_active = p->n_active; m->comp_exp = p->comp_exp;
+    for (int i = 0; i < MCSAS_MAX_PARAMS; ++i) m->params[i] = p->params[i];
+    for (int c = 0; c < MCSAS_MAX_ACTIVE; ++c) {
+        m->active_index[c] = c < p->n_active ? p->active_index[c] : -1;
+        m->clip_lo[c] = p->clip_lo[c]; m->clip_hi[c] = p->clip_hi[c];
+        if (c < p->n_active && (p->active_index[c] < 0 || p->active_index[c] >= MCSAS_MAX_PARAMS))
+            return fail(MCSAS_EINVAL, "active_index[%d]=%d out of range", c, p->active_index[c]);
+    }
+    m->int_div = model_int_div(p);
+    if (p->model_id != MCSAS_MODEL_SPHERE && (m->int_div < 2 || m->int_div > 4096))
+        return fail(MCSAS_EINVAL, "intDiv %d unsupported (2..4096)", m->int_div);
+    return MCSAS_OK;
+}
+
+static int table_doubles_host(int model_id, int K) { return model_id == MCSAS_MODEL_SPHERE ? 0 : 2 * K; }
+
+static int select_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MCSAS_ENODEV, "no HIP device available");
+    if (device >= n) return fail(MCSAS_ENODEV, "device %d requested, %d present", device, n);
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    return MCSAS_OK;
+}
+
+// ------------------------------------------------------------------------------ plan
+struct mcsas_plan {
+    mcsas_problem prob;
+    ChainArgs args;
+    int qpl = 0, waves = 1, use_cache = 1, dev = 0;
+    size_t lds_bytes = 0;
+    double *d_q = nullptr, *d_w = nullptr, *d_wI = nullptr, *d_I = nullptr;
+    double *d_rset = nullptr, *d_cache = nullptr, *d_fit = nullptr, *d_replay = nullptr;
+    ChainOut *d_out = nullptr;
+    int32_t *h_stop = nullptr;          // pinned + mapped: the kernels poll it
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr;
+    bool launched = false;
+    double last_ms = 0.;
+    int64_t last_steps = 0;
+    WgGeom wg{};
+};
+
+template <int M, int QPL>
+static void *wave_kernel_ptr(bool cache) {
+    return cache ? (void *)chain_wave_kernel<M, QPL, true> : (void *)chain_wave_kernel<M, QPL, false>;
+}
+template <int M>
+static void *wave_kernel_for_qpl(int qpl, bool cache) {
+    switch (qpl) {
+        case 1: return wave_kernel_ptr<M, 1>(cache);
+        case 2: return wave_kernel_ptr<M, 2>(cache);
+        case 4: return wave_kernel_ptr<M, 4>(cache);
+        case 8: return wave_kernel_ptr<M, 8>(cache);
+        case 16: return wave_kernel_ptr<M, 16>(cache);
+        default: return nullptr;
+    }
+}
+static void *wave_kernel_for(int model, int qpl, bool cache) {
+    switch (model) {
+        case MCSAS_MODEL_SPHERE: return wave_kernel_for_qpl<MCSAS_MODEL_SPHERE>(qpl, cache);
+        case MCSAS_MODEL_CYL_ISO: return wave_kernel_for_qpl<MCSAS_MODEL_CYL_ISO>(qpl, cache);
+        case MCSAS_MODEL_ELL_CS: return wave_kernel_for_qpl<MCSAS_MODEL_ELL_CS>(qpl, cache);
+        default: return nullptr;
+    }
+}
+static void *wg_kernel_for(int model) {
+    switch (model) {
+        case MCSAS_MODEL_SPHERE: return (void *)chain_wg_kernel<MCSAS_MODEL_SPHERE>;
+        case MCSAS_MODEL_CYL_ISO: return (void *)chain_wg_kernel<MCSAS_MODEL_CYL_ISO>;
+        case MCSAS_MODEL_ELL_CS: return (void *)chain_wg_kernel<MCSAS_MODEL_ELL_CS>;
+        default: return nullptr;
+    }
+}
+
+extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
+    if (!pl) return;
+    hipFree(pl->d_q); hipFree(pl->d_w); hipFree(pl->d_wI); hipFree(pl->d_I);
+    hipFree(pl->d_rset); hipFree(pl->d_cache); hipFree(pl->d_fit); hipFree(pl->d_replay); hipFree(pl->d_out);
+    if (pl->h_stop) hipHostFree(pl->h_stop);
+    if (pl->ev0) hipEventDestroy(pl->ev0);
+    if (pl->ev1) hipEventDestroy(pl->ev1);
+    delete pl;
+}
+
+extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
+    if (!p || !out) return fail(MCSAS_EINVAL, "null argument");
+    *out = nullptr;
+    if (p->struct_size != sizeof(mcsas_problem))
+        return fail(MCSAS_EINVAL, "mcsas_problem size %u, library expects %zu (ABI mismatch)", p->struct_size, sizeof(mcsas_problem));
+    if (p->nq < 1 || !p->q || !p->intensity || !p->sigma) return fail(MCSAS_EINVAL, "nq/q/intensity/sigma missing");
+    if (p->n_contrib < 1 || p->n_reps < 1) return fail(MCSAS_EINVAL, "n_contrib and n_reps must be >= 1");
+    if (p->max_iter < 0 || p->max_retries < 0) return fail(MCSAS_EINVAL, "max_iter/max_retries negative");
+    if (p->replay_stream && p->replay_len < 1) return fail(MCSAS_EINVAL, "replay_len must be >= 1");
+    ModelArgs margs;
+    int rc = fill_model_args(p, &margs);
+    if (rc) return rc;
+    for (int c = 0; c < p->n_active; ++c)
+        if (p->gen_kind[c] < 0 || p->gen_kind[c] > 3) return fail(MCSAS_EINVAL, "gen_kind[%d]=%d", c, p->gen_kind[c]);
+    rc = select_device(p->device);
+    if (rc) return rc;
+
+    mcsas_plan *pl = new mcsas_plan();
+    pl->prob = *p;
+    pl->prob.q = pl->prob.intensity = pl->prob.sigma = nullptr;     // host arrays are not retained
+    pl->prob.replay_stream = nullptr;
+    hipGetDevice(&pl->dev);
+#define PCHK(expr)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            int c_ = fail(e_ == hipErrorOutOfMemory ? MCSAS_ENOMEM : MCSAS_EHIP, "%s: %s (%s:%d)", #expr, \
+                          hipGetErrorString(e_), __FILE__, __LINE__);                                \
+            mcsas_hip_plan_destroy(pl);                                                              \
+            return c_;                                                                               \
+        }                                                                                            \
+    } while (0)
+
+    // q slots per lane: power of two so the kernels are fully unrolled
+    int qpl = 1;
+    while (qpl * WAVE < p->nq) qpl *= 2;
+    const int waves = p->waves_per_chain > 0 ? p->waves_per_chain : 1;
+    if (waves == 1 && qpl > 16) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 1024 needs waves_per_chain > 1", p->nq); }
+    const int qpad = qpl * WAVE;
+    pl->qpl = qpl; pl->waves = waves;
+
+    // padded data vectors; sigma == 0 -> 1 (backgroundscalingfit.py:117)
+    std::vector<double> hq(qpad), hw(qpad, 0.), hwI(qpad, 0.), hI(qpad, 0.);
+    double Sw = 0, SI = 0, SII = 0, Ss2 = 0;
+    for (int i = 0; i < qpad; ++i) hq[i] = p->q[i < p->nq ? i : 0];
+    for (int i = 0; i < p->nq; ++i) {
+        double e = p->sigma[i] == 0.0 ? 1.0 : p->sigma[i];
+        double w = 1.0 / (e * e);
+        hw[i] = w; hwI[i] = w * p->intensity[i]; hI[i] = p->intensity[i];
+        Sw += w; SI += w * p->intensity[i]; SII += w * p->intensity[i] * p->intensity[i]; Ss2 += e * e;
+    }
+    const size_t vb = sizeof(double) * qpad;
+    PCHK(hipMalloc(&pl->d_q, vb)); PCHK(hipMalloc(&pl->d_w, vb)); PCHK(hipMalloc(&pl->d_wI, vb)); PCHK(hipMalloc(&pl->d_I, vb));
+    PCHK(hipMemcpy(pl->d_q, hq.data(), vb, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(pl->d_w, hw.data(), vb, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(pl->d_wI, hwI.data(), vb, hipMemcpyHostToDevice));
+    PCHK(hipMemcpy(pl->d_I, hI.data(), vb, hipMemcpyHostToDevice));
+
+    const size_t R = p->n_reps, N = p->n_contrib, P = p->n_active;
+    PCHK(hipMalloc(&pl->d_rset, sizeof(double) * R * N * P));
+    PCHK(hipMalloc(&pl->d_fit, sizeof(double) * R * qpad));
+    PCHK(hipMalloc(&pl->d_out, sizeof(ChainOut) * R));
+    PCHK(hipMemset(pl->d_out, 0, sizeof(ChainOut) * R));
+
+    // per-contribution intensity rows: the workgroup kernel adds one spare row per window slot
+    int cache_rows = (int)N;
+    if (waves > 1) {
+        int rcg = wg_geometry(p->nq, (int)N, table_doubles_host(p->model_id, margs.int_div), waves, &pl->wg);
+        if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: problem does not fit LDS (nq=%d)", p->nq); }
+        cache_rows = (int)N + pl->wg.window;
+    }
+    size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
+    int use_cache = p->cache_intensities;
+    if (use_cache < 0 || waves > 1) {
+        size_t fr = 0, tot = 0;
+        PCHK(hipMemGetInfo(&fr, &tot));
+        use_cache = cache_bytes < fr / 2;
+        if (waves > 1 && !use_cache) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_ENOMEM, "intensity cache (%zu MB) does not fit", cache_bytes >> 20); }
+    }
+    pl->use_cache = use_cache;
+    if (use_cache) PCHK(hipMalloc(&pl->d_cache, cache_bytes));
+
+    if (p->replay_stream) {
+        size_t rb = sizeof(double) * R * (size_t)p->replay_len;
+        PCHK(hipMalloc(&pl->d_replay, rb));
+        PCHK(hipMemcpy(pl->d_replay, p->replay_stream, rb, hipMemcpyHostToDevice));
+    }
+    PCHK(hipHostMalloc((void **)&pl->h_stop, sizeof(int32_t), hipHostMallocMapped));
+    *pl->h_stop = 0;
+    int32_t *d_stop = nullptr;
+    PCHK(hipHostGetDevicePointer((void **)&d_stop, pl->h_stop, 0));
+    PCHK(hipEventCreate(&pl->ev0)); PCHK(hipEventCreate(&pl->ev1));
+
+    ChainArgs &a = pl->args;
+    memset(&a, 0, sizeof a);
+    a.model = margs;
+    a.nq = p->nq; a.qpad = qpad;
+    a.q = pl->d_q; a.w = pl->d_w; a.wI = pl->d_wI; a.I = pl->d_I;
+    a.Sw = Sw; a.SI = SI; a.SII = SII; a.Ssig2 = Ss2;
+    a.n_contrib = p->n_contrib; a.n_reps = p->n_reps;
+    a.find_bg = p->find_background != 0; a.pos_bg = p->positive_background != 0;
+    a.start_from_min = p->start_from_minimum != 0; a.max_retries = p->max_retries;
+    a.max_iter = p->max_iter; a.conv_crit = p->conv_crit;
+    for (int c = 0; c < MCSAS_MAX_ACTIVE; ++c) {
+        a.gen_lo[c] = p->gen_lo[c]; a.gen_hi[c] = p->gen_hi[c]; a.start_value[c] = p->start_value[c];
+        a.gen_kind[c] = p->gen_kind[c];
+    }
+    a.seed = p->seed; a.rep_offset = p->rep_offset;
+    a.replay = pl->d_replay; a.replay_len = p->replay_len;
+    a.stop_flag = d_stop;
+    a.rset = pl->d_rset; a.cache = pl->d_cache; a.cache_rows = cache_rows; a.fit = pl->d_fit; a.out = pl->d_out;
+
+    if (waves == 1) {
+        pl->lds_bytes = sizeof(double) * (3 * (size_t)qpad + table_doubles_host(p->model_id, margs.int_div));
+        if (!wave_kernel_for(p->model_id, qpl, use_cache)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no kernel for model %d qpl %d", p->model_id, qpl); }
+    } else {
+        pl->lds_bytes = pl->wg.lds_bytes;
+    }
+    if (pl->lds_bytes > 160 * 1024) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "LDS need %zu B > 160 KiB", pl->lds_bytes); }
+    *out = pl;
+    return MCSAS_OK;
+#undef PCHK
+}
+
+extern "C" int mcsas_hip_plan_reseed(mcsas_plan *pl, uint64_t seed, int32_t rep_offset) {
+    if (!pl) return fail(MCSAS_EINVAL, "null plan");
+    pl->args.seed = seed; pl->args.rep_offset = rep_offset;
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
+    if (!pl) return fail(MCSAS_EINVAL, "null plan");
+    HIPCHK(hipSetDevice(pl->dev));
+    hipStream_t st = (hipStream_t)hip_stream;
+    *pl->h_stop = (pl->prob.stop && *pl->prob.stop) ? 1 : 0;
+    void *kargs[] = {(void *)&pl->args};
+    void *fn;
+    dim3 grid(pl->prob.n_reps), block;
+    if (pl->waves == 1) {
+        fn = wave_kernel_for(pl->prob.model_id, pl->qpl, pl->use_cache);
+        block = dim3(WAVE);
+    } else {
+        fn = wg_kernel_for(pl->prob.model_id);
+        block = dim3(WAVE * pl->waves);
+    }
+    if (pl->lds_bytes > 64 * 1024)
+        HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
+    HIPCHK(hipEventRecord(pl->ev0, st));
+    if (pl->waves == 1) {
+        HIPCHK(hipLaunchKernel(fn, grid, block, kargs, pl->lds_bytes, st));
+    } else {
+        void *kargs2[] = {(void *)&pl->args, (void *)&pl->wg};
+        HIPCHK(hipLaunchKernel(fn, grid, block, kargs2, pl->lds_bytes, st));
+    }
+    HIPCHK(hipEventRecord(pl->ev1, st));
+    pl->stream = st; pl->launched = true;
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
+    if (!pl) return fail(MCSAS_EINVAL, "null plan");
+    if (!pl->launched) return fail(MCSAS_EINVAL, "plan was not launched");
+    if (res && res->struct_size != sizeof(mcsas_result))
+        return fail(MCSAS_EINVAL, "mcsas_result size %u, library expects %zu", res->struct_size, sizeof(mcsas_result));
+    HIPCHK(hipSetDevice(pl->dev));
+    // wait, forwarding the caller's stop word to the device-visible one (McSAS.stop, mcsas.py:357)
+    for (;;) {
+        hipError_t q = hipEventQuery(pl->ev1);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail(MCSAS_EHIP, "kernel failed: %s", hipGetErrorString(q));
+        if (pl->prob.stop && *pl->prob.stop) *pl->h_stop = 1;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    HIPCHK(hipEventSynchronize(pl->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, pl->ev0, pl->ev1));
+    pl->last_ms = ms;
+    const size_t R = pl->prob.n_reps, N = pl->prob.n_contrib, P = pl->prob.n_active, Q = pl->prob.nq, qpad = pl->args.qpad;
+    std::vector<ChainOut> ho(R);
+    HIPCHK(hipMemcpy(ho.data(), pl->d_out, sizeof(ChainOut) * R, hipMemcpyDeviceToHost));
+    int64_t steps = 0; int ovf = 0;
+    for (size_t r = 0; r < R; ++r) { steps += ho[r].total_steps; ovf |= ho[r].stream_overflow; }
+    pl->last_steps = steps;
+    if (res) {
+        if (res->contribs) {
+            std::vector<double> hr(R * N * P);
+            HIPCHK(hipMemcpy(hr.data(), pl->d_rset, sizeof(double) * hr.size(), hipMemcpyDeviceToHost));
+            for (size_t r = 0; r < R; ++r)
+                for (size_t n = 0; n < N; ++n)
+                    for (size_t p = 0; p < P; ++p) res->contribs[(n * P + p) * R + r] = hr[(r * N + n) * P + p];
+        }
+        if (res->fit) {
+            std::vector<double> hf(R * qpad);
+            HIPCHK(hipMemcpy(hf.data(), pl->d_fit, sizeof(double) * hf.size(), hipMemcpyDeviceToHost));
+            for (size_t r = 0; r < R; ++r)
+                for (size_t k = 0; k < Q; ++k) res->fit[k * R + r] = hf[r * qpad + k];
+        }
+        for (size_t r = 0; r < R; ++r) {
+            if (res->chisq) res->chisq[r] = ho[r].chisq;
+            if (res->scaling) res->scaling[r] = ho[r].scaling;
+            if (res->background) res->background[r] = ho[r].background;
+            if (res->num_iter) res->num_iter[r] = ho[r].num_iter;
+            if (res->num_moves) res->num_moves[r] = ho[r].num_moves;
+            if (res->attempts) res->attempts[r] = ho[r].attempts;
+            if (res->converged) res->converged[r] = ho[r].converged;
+            if (res->seconds) res->seconds[r] = ho[r].seconds;
+            if (res->draws) res->draws[r] = ho[r].draws;
+        }
+    }
+    if (ovf) return fail(MCSAS_ESTREAM, "replay stream exhausted (replay_len=%lld)", (long long)pl->prob.replay_len);
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_plan_last_ms(mcsas_plan *pl, double *ms) {
+    if (!pl || !ms) return fail(MCSAS_EINVAL, "null argument");
+    *ms = pl->last_ms;
+    return MCSAS_OK;
+}
+extern "C" int mcsas_hip_plan_total_steps(mcsas_plan *pl, int64_t *steps) {
+    if (!pl || !steps) return fail(MCSAS_EINVAL, "null argument");
+    *steps = pl->last_steps;
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_analyse(const mcsas_problem *p, mcsas_result *res) {
+    if (!res) return fail(MCSAS_EINVAL, "null result");
+    mcsas_plan *pl = nullptr;
+    int rc = mcsas_hip_plan_create(p, &pl);
+    if (rc) return rc;
+    rc = mcsas_hip_plan_launch(pl, nullptr);
+    if (!rc) rc = mcsas_hip_plan_fetch(pl, res);
+    mcsas_hip_plan_destroy(pl);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------ model.calc
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(T) * (n ? n : 1)); }
+};
+
+extern "C" int mcsas_hip_model_calc(const mcsas_problem *p, const double *pset, int32_t n, double *cum_int,
+                                    double *vset, double *wset, double *sset, double *rows) {
+    if (!p || !pset || n < 1 || !p->q || p->nq < 1) return fail(MCSAS_EINVAL, "bad argument");
+    ModelArgs m;
+    int rc = fill_model_args(p, &m);
+    if (rc) return rc;
+    rc = select_device(p->device);
+    if (rc) return rc;
+    const size_t Q = p->nq, P = p->n_active;
+    DevBuf<double> dq, dp, dr, dv, dw, ds, dc;
+    HIPCHK(dq.alloc(Q)); HIPCHK(dp.alloc(n * P)); HIPCHK(dr.alloc((size_t)n * Q));
+    HIPCHK(dv.alloc(n)); HIPCHK(dw.alloc(n)); HIPCHK(ds.alloc(n)); HIPCHK(dc.alloc(Q));
+    HIPCHK(hipMemcpy(dq.p, p->q, sizeof(double) * Q, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dp.p, pset, sizeof(double) * n * P, hipMemcpyHostToDevice));
+    size_t lds = sizeof(double) * table_doubles_host(p->model_id, m.int_div);
+    switch (p->model_id) {
+        case MCSAS_MODEL_SPHERE:
+            model_rows_kernel<MCSAS_MODEL_SPHERE><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
+        case MCSAS_MODEL_CYL_ISO:
+            model_rows_kernel<MCSAS_MODEL_CYL_ISO><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
+        case MCSAS_MODEL_ELL_CS:
+            model_rows_kernel<MCSAS_MODEL_ELL_CS><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
+        default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
+    }
+    HIPCHK(hipGetLastError());
+    rows_cumsum_kernel<<<(p->nq + 255) / 256, 256>>>(p->nq, n, dr.p, dc.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    if (cum_int) HIPCHK(hipMemcpy(cum_int, dc.p, sizeof(double) * Q, hipMemcpyDeviceToHost));
+    if (vset) HIPCHK(hipMemcpy(vset, dv.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (wset) HIPCHK(hipMemcpy(wset, dw.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (sset) HIPCHK(hipMemcpy(sset, ds.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (rows) HIPCHK(hipMemcpy(rows, dr.p, sizeof(double) * n * Q, hipMemcpyDeviceToHost));
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_bgfit(int32_t nq, const double *I, const double *sigma, const double *C, int32_t find_bg,
+                               int32_t pos_bg, int32_t num_params, int32_t device, double out[4]) {
+    if (nq < 1 || !I || !sigma || !C || !out) return fail(MCSAS_EINVAL, "bad argument");
+    int rc = select_device(device);
+    if (rc) return rc;
+    DevBuf<double> dI, dS, dC, dO;
+    HIPCHK(dI.alloc(nq)); HIPCHK(dS.alloc(nq)); HIPCHK(dC.alloc(nq)); HIPCHK(dO.alloc(4));
+    HIPCHK(hipMemcpy(dI.p, I, sizeof(double) * nq, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dS.p, sigma, sizeof(double) * nq, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dC.p, C, sizeof(double) * nq, hipMemcpyHostToDevice));
+    bgfit_kernel<<<1, WAVE>>>(nq, dI.p, dS.p, dC.p, find_bg != 0, pos_bg != 0, num_params, dO.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dO.p, sizeof(double) * 4, hipMemcpyDeviceToHost));
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_observability(const mcsas_problem *p, const double *contribs, const double *scaling,
+                                       const double *vol_frac, double *min_req_vol) {
+    if (!p || !contribs || !scaling || !vol_frac || !min_req_vol || !p->q || !p->sigma) return fail(MCSAS_EINVAL, "bad argument");
+    ModelArgs m;
+    int rc = fill_model_args(p, &m);
+    if (rc) return rc;
+    rc = select_device(p->device);
+    if (rc) return rc;
+    const size_t Q = p->nq, P = p->n_active, N = p->n_contrib, R = p->n_reps;
+    DevBuf<double> dq, dsg, dc, dsc, dvf, dm;
+    HIPCHK(dq.alloc(Q)); HIPCHK(dsg.alloc(Q)); HIPCHK(dc.alloc(N * P * R)); HIPCHK(dsc.alloc(R));
+    HIPCHK(dvf.alloc(N * R)); HIPCHK(dm.alloc(N * R));
+    HIPCHK(hipMemcpy(dq.p, p->q, sizeof(double) * Q, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dsg.p, p->sigma, sizeof(double) * Q, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dc.p, contribs, sizeof(double) * N * P * R, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dsc.p, scaling, sizeof(double) * R, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dvf.p, vol_frac, sizeof(double) * N * R, hipMemcpyHostToDevice));
+    size_t lds = sizeof(double) * table_doubles_host(p->model_id, m.int_div);
+    dim3 grid((unsigned)N, (unsigned)R);
+    switch (p->model_id) {
+        case MCSAS_MODEL_SPHERE:
+            observability_kernel<MCSAS_MODEL_SPHERE><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
+        case MCSAS_MODEL_CYL_ISO:
+            observability_kernel<MCSAS_MODEL_CYL_ISO><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
+        case MCSAS_MODEL_ELL_CS:
+            observability_kernel<MCSAS_MODEL_ELL_CS><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
+        default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(min_req_vol, dm.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int mcsas_hip_abi_version(void) { return MCSAS_ABI_VERSION; }
+extern "C" const char *mcsas_hip_last_error(void) { return g_err.c_str(); }

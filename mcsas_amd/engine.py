@@ -1,0 +1,232 @@
+"""Array-level front of the HIP library: builds `mcsas_problem` blocks and runs them.
+
+This is the thin layer the class-level mirror (`mcsas_amd.mcsas.McSAS`, `mcsas_amd.scatteringmodels`)
+and the reference-side binding shown in INTEGRATION.md both sit on.  Everything numerical happens
+in libmcsas_hip.so; nothing here evaluates a form factor or a chi-squared on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import MAX_ACTIVE, MAX_PARAMS, Problem, Result, as_dp, check, f64
+
+MODEL_SPHERE, MODEL_CYL_ISO, MODEL_ELL_CS, MODEL_KHOLODENKO = 0, 1, 2, 3
+GEN_UNIFORM, GEN_EXP1, GEN_EXP2, GEN_EXP3 = 0, 1, 2, 3
+INT64_MAX = (1 << 63) - 1
+
+
+@dataclass
+class ModelSetup:
+    """A configured scattering model, flattened: full parameter vector (order of the reference's
+    `parameters` tuple) plus, per active parameter, generator range/kind and clip range."""
+    model_id: int
+    params: np.ndarray                 # all parameter values (SI)
+    active_index: tuple                # ascending indices into params
+    gen_lo: np.ndarray                 # activeRange ∩ valueRange
+    gen_hi: np.ndarray
+    gen_kind: tuple
+    clip_lo: np.ndarray                # valueRange
+    clip_hi: np.ndarray
+    start_value: np.ndarray = None     # startFromMinimum fill (mcsas.py:310-315)
+
+    @property
+    def n_active(self):
+        return len(self.active_index)
+
+
+@dataclass
+class Settings:
+    """The algorithm parameters of mcsas/mcsasparameters.json that reach the hot path."""
+    n_contrib: int = 300
+    n_reps: int = 10
+    max_iter: int = 100000
+    comp_exp: float = 0.6666666
+    conv_crit: float = 1.0
+    find_background: bool = True
+    positive_background: bool = False
+    start_from_minimum: bool = False
+    max_retries: int = 5
+    show_incomplete: bool = False
+    # execution knobs (no reference counterpart)
+    seed: int = 0
+    rep_offset: int = 0
+    device: int = -1
+    waves_per_chain: int = 0
+    cache_intensities: int = -1
+
+
+def _fill(arr, values, n):
+    for i in range(n):
+        arr[i] = values[i]
+
+
+class HipProblem:
+    """Owns the numpy buffers a `mcsas_problem` points at (ctypes does not keep them alive)."""
+
+    def __init__(self, model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None):
+        if model.n_active < 1 or model.n_active > MAX_ACTIVE:
+            raise ValueError("1..%d active parameters supported, got %d" % (MAX_ACTIVE, model.n_active))
+        self.q, self.I, self.sigma = f64(q).ravel(), f64(intensity).ravel(), f64(sigma).ravel()
+        if not (len(self.q) == len(self.I) == len(self.sigma)):
+            raise ValueError("q, intensity and sigma must have the same length")
+        self.model, self.st = model, st
+        p = Problem()
+        p.struct_size = C.sizeof(Problem)
+        p.model_id = model.model_id
+        p.nq = len(self.q)
+        p.q, p.intensity, p.sigma = as_dp(self.q), as_dp(self.I), as_dp(self.sigma)
+        _fill(p.params, list(model.params) + [0.0] * (MAX_PARAMS - len(model.params)), MAX_PARAMS)
+        P = model.n_active
+        p.n_active = P
+        _fill(p.active_index, model.active_index, P)
+        _fill(p.gen_lo, model.gen_lo, P); _fill(p.gen_hi, model.gen_hi, P)
+        _fill(p.gen_kind, model.gen_kind, P)
+        _fill(p.clip_lo, model.clip_lo, P); _fill(p.clip_hi, model.clip_hi, P)
+        sv = model.start_value if model.start_value is not None else np.zeros(P)
+        _fill(p.start_value, sv, P)
+        p.n_contrib, p.n_reps = int(st.n_contrib), int(st.n_reps)
+        p.max_iter = int(min(float(st.max_iter), float(INT64_MAX // 2)))
+        p.comp_exp, p.conv_crit = float(st.comp_exp), float(st.conv_crit)
+        p.max_retries = int(st.max_retries)
+        p.find_background = int(bool(st.find_background))
+        p.positive_background = int(bool(st.positive_background))
+        p.start_from_minimum = int(bool(st.start_from_minimum))
+        p.seed = int(st.seed) & 0xFFFFFFFFFFFFFFFF
+        p.rep_offset = int(st.rep_offset)
+        self.replay = None
+        if replay is not None:
+            self.replay = f64(replay).reshape(p.n_reps, -1)
+            p.replay_stream = as_dp(self.replay)
+            p.replay_len = self.replay.shape[1]
+        self.stop = stop                      # ctypes c_int32 the caller may set to 1
+        if stop is not None:
+            p.stop = C.pointer(stop)
+        p.device = int(st.device)
+        p.waves_per_chain = int(st.waves_per_chain)
+        p.cache_intensities = int(st.cache_intensities)
+        self.c = p
+
+
+class ChainResults:
+    """numpy-backed `mcsas_result`."""
+
+    def __init__(self, n_contrib, n_active, n_reps, nq):
+        self.contribs = np.zeros((n_contrib, n_active, n_reps))
+        self.fit = np.zeros((nq, n_reps))
+        self.chisq = np.zeros(n_reps); self.scaling = np.zeros(n_reps); self.background = np.zeros(n_reps)
+        self.num_iter = np.zeros(n_reps, dtype=np.int64); self.num_moves = np.zeros(n_reps, dtype=np.int64)
+        self.attempts = np.zeros(n_reps, dtype=np.int32); self.converged = np.zeros(n_reps, dtype=np.int32)
+        self.seconds = np.zeros(n_reps); self.draws = np.zeros(n_reps, dtype=np.int64)
+        r = Result()
+        r.struct_size = C.sizeof(Result)
+        r.contribs, r.fit = as_dp(self.contribs), as_dp(self.fit)
+        r.chisq, r.scaling, r.background = as_dp(self.chisq), as_dp(self.scaling), as_dp(self.background)
+        r.num_iter = self.num_iter.ctypes.data_as(C.POINTER(C.c_int64))
+        r.num_moves = self.num_moves.ctypes.data_as(C.POINTER(C.c_int64))
+        r.attempts = self.attempts.ctypes.data_as(C.POINTER(C.c_int32))
+        r.converged = self.converged.ctypes.data_as(C.POINTER(C.c_int32))
+        r.seconds = as_dp(self.seconds)
+        r.draws = self.draws.ctypes.data_as(C.POINTER(C.c_int64))
+        self.c = r
+
+
+def analyse(model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None) -> ChainResults:
+    """All repetitions of McSAS.analyse (mcsas.py:214-262) in one kernel launch."""
+    lib = _lib.load()
+    prob = HipProblem(model, q, intensity, sigma, st, replay, stop)
+    res = ChainResults(st.n_contrib, model.n_active, st.n_reps, len(prob.q))
+    check(lib.mcsas_hip_analyse(C.byref(prob.c), C.byref(res.c)))
+    return res
+
+
+class Plan:
+    """Resident plan: data and workspaces stay in HBM; launch/fetch can be repeated (bench.py)."""
+
+    def __init__(self, model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None):
+        self.lib = _lib.load()
+        self.prob = HipProblem(model, q, intensity, sigma, st, replay, stop)
+        self.h = C.c_void_p()
+        check(self.lib.mcsas_hip_plan_create(C.byref(self.prob.c), C.byref(self.h)))
+
+    def launch(self, stream=None):
+        check(self.lib.mcsas_hip_plan_launch(self.h, C.c_void_p(stream or 0)))
+
+    def fetch(self, want_arrays=True):
+        st = self.prob.st
+        res = ChainResults(st.n_contrib, self.prob.model.n_active, st.n_reps, len(self.prob.q)) if want_arrays else None
+        check(self.lib.mcsas_hip_plan_fetch(self.h, C.byref(res.c) if res is not None else None))
+        return res
+
+    def reseed(self, seed, rep_offset=0):
+        check(self.lib.mcsas_hip_plan_reseed(self.h, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_int32(rep_offset)))
+
+    @property
+    def last_ms(self):
+        v = C.c_double()
+        check(self.lib.mcsas_hip_plan_last_ms(self.h, C.byref(v)))
+        return v.value
+
+    @property
+    def total_steps(self):
+        v = C.c_int64()
+        check(self.lib.mcsas_hip_plan_total_steps(self.h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self.h:
+            self.lib.mcsas_hip_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def model_calc(model: ModelSetup, q, pset, comp_exp, want_rows=False, device=-1):
+    """ScatteringModel.calc(data, pset, compensationExponent) (scatteringmodel.py:79-109) on the GPU.
+    Returns cumInt, vset, wset, sset (and rows[n][Q] when asked)."""
+    lib = _lib.load()
+    q = f64(q).ravel()
+    pset = f64(pset).reshape(-1, model.n_active)
+    st = Settings(n_contrib=1, n_reps=1, comp_exp=comp_exp, device=device)
+    prob = HipProblem(model, q, np.ones_like(q), np.ones_like(q), st)
+    n = len(pset)
+    cum = np.zeros(len(q)); vset = np.zeros(n); wset = np.zeros(n); sset = np.zeros(n)
+    rows = np.zeros((n, len(q))) if want_rows else None
+    check(lib.mcsas_hip_model_calc(C.byref(prob.c), as_dp(pset), n, as_dp(cum), as_dp(vset), as_dp(wset),
+                                   as_dp(sset), as_dp(rows) if rows is not None else None))
+    return (cum, vset, wset, sset, rows) if want_rows else (cum, vset, wset, sset)
+
+
+def bgfit(intensity, sigma, model_int, find_background=True, positive_background=False, num_params=1, device=-1):
+    """BackgroundScalingFit.calc (backgroundscalingfit.py:112-139): returns (sc[2], conval, aGoFs)."""
+    lib = _lib.load()
+    I, s, c = f64(intensity).ravel(), f64(sigma).ravel(), f64(model_int).ravel()
+    out = np.zeros(4)
+    check(lib.mcsas_hip_bgfit(len(I), as_dp(I), as_dp(s), as_dp(c), int(find_background), int(positive_background),
+                              int(num_params), int(device), as_dp(out)))
+    return out[:2].copy(), float(out[2]), float(out[3])
+
+
+def observability(model: ModelSetup, q, sigma, contribs, scaling, vol_frac, comp_exp, device=-1):
+    """Per-contribution minimum visible volume fraction (mcsas.py:575-590) for all reps."""
+    lib = _lib.load()
+    contribs = f64(contribs)
+    N, P, R = contribs.shape
+    q = f64(q).ravel(); sigma = f64(sigma).ravel()
+    st = Settings(n_contrib=N, n_reps=R, comp_exp=comp_exp, device=device)
+    prob = HipProblem(model, q, np.ones_like(q), sigma, st)
+    scaling = f64(scaling).ravel(); vol_frac = f64(vol_frac).reshape(N, R)
+    out = np.zeros((N, R))
+    check(lib.mcsas_hip_observability(C.byref(prob.c), as_dp(contribs), as_dp(scaling), as_dp(vol_frac), as_dp(out)))
+    return out
+
+
+def device_count():
+    return _lib.load().mcsas_hip_device_count()

@@ -1,0 +1,183 @@
+"""McSAS: drop-in mirror of the reference's algorithm object for the Monte-Carlo path.
+
+Same attributes and calls as `mcsas.mcsas.McSAS` (mcsas/mcsas.py:31-179): `McSAS.factory()()`,
+`.data`, `.model`, `.result`, `.stop`, the settings as callable parameters (`numContribs()`,
+`maxIterations.value()`, `convergenceCriterion.setValue(...)` ...), `calc()`, `analyse()`,
+`histogram()`.  `analyse()` runs every repetition as one MI355X kernel launch; nothing is
+evaluated on the CPU.  Plotting, HDF5/pickle output and the GUI hooks stay with the reference.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+
+import numpy as np
+
+from . import engine
+from .parameter import isActiveFitParam
+from .scatteringmodels import setup_from_model
+
+
+class _Setting(object):
+    """Algorithm parameter with the reference's accessors (`p()`, `p.value()`, `p.setValue(v)`)."""
+
+    def __init__(self, name, default, valueRange=None):
+        self._name, self._value, self._range = name, default, valueRange
+
+    def name(self):
+        return self._name
+
+    def value(self):
+        return self._value
+
+    __call__ = value
+
+    def setValue(self, v):
+        if self._range is not None and not isinstance(v, bool):
+            v = min(max(v, self._range[0]), self._range[1])
+        self._value = type(self._value)(v) if not isinstance(self._value, bool) else bool(v)
+
+
+# mcsas/mcsasparameters.json:2-103
+_DEFAULTS = (
+    ("numContribs", 300, (1, 1e6)), ("numReps", 10, (1, 1e6)), ("maxIterations", 1e5, (1, 1e100)),
+    ("compensationExponent", 0.6666666, None), ("convergenceCriterion", 1.0, (0, np.inf)),
+    ("findBackground", True, None), ("positiveBackground", False, None),
+    ("startFromMinimum", False, None), ("maxRetries", 5, (1, 100)), ("showIncomplete", False, None),
+)
+
+
+class McSAS(object):
+    data = None
+    model = None
+    result = None
+
+    @classmethod
+    def factory(cls):                                        # mcsas.py:143-147
+        return cls
+
+    def __init__(self, seed=None, device=-1, wavesPerChain=0):
+        for name, default, rng in _DEFAULTS:
+            setattr(self, name, _Setting(name, default, rng))
+        self.seed = seed
+        self.device = device
+        self.wavesPerChain = wavesPerChain
+        self._stop = C.c_int32(0)
+        self.details = None
+
+    # McSAS.stop is polled once per step in the reference (mcsas.py:357); here the word is
+    # forwarded to the running kernel by the library
+    @property
+    def stop(self):
+        return bool(self._stop.value)
+
+    @stop.setter
+    def stop(self, flag):
+        self._stop.value = 1 if flag else 0
+
+    def calc(self, **kwargs):                                # mcsas.py:149-179
+        self.result = []
+        self.stop = False
+        assert self.data is not None
+        if self.model is None:
+            raise ValueError("McSAS.model is not set")
+        if not self.model.paramCount():
+            logging.warning("No parameters to analyse given! Breaking up.")
+            return
+        self.analyse()
+        if not len(self.result):
+            return
+        self.histogram()
+
+    def _settings(self, numContribs, numReps):
+        seed = self.seed
+        if seed is None:                                     # reference: unseeded global MT19937
+            seed = int.from_bytes(os.urandom(8), "little")
+        return engine.Settings(
+            n_contrib=int(numContribs), n_reps=int(numReps), max_iter=self.maxIterations.value(),
+            comp_exp=self.compensationExponent(), conv_crit=self.convergenceCriterion(),
+            find_background=self.findBackground.value(), positive_background=self.positiveBackground.value(),
+            start_from_minimum=self.startFromMinimum(), max_retries=int(self.maxRetries()),
+            show_incomplete=self.showIncomplete(), seed=seed, device=self.device,
+            waves_per_chain=self.wavesPerChain)
+
+    def analyse(self, replay=None):                          # mcsas.py:191-285
+        if self.result is None:
+            self.result = []
+        data, model = self.data, self.model
+        if not any(isActiveFitParam(p) for p in model.params()):
+            raise NotImplementedError("no active fit parameter: nothing for the Monte-Carlo kernels to do")
+        numContribs, numReps = self.numContribs(), self.numReps()
+        st = self._settings(numContribs, numReps)
+        setup = setup_from_model(model, data)
+        res = engine.analyse(setup, data.q, data.f.binnedData, data.f.binnedDataU, st,
+                             replay=replay, stop=self._stop)
+        self.details = res
+        if (res.converged == 0).any():                       # mcsas.py:221-230 / :240-245
+            if self.stop:
+                logging.warning("Stop button pressed, exiting...")
+            else:
+                logging.warning("Could not reach optimization criterion within {0} attempts, exiting..."
+                                .format(self.maxRetries() + 2))
+            if not self.showIncomplete():
+                return
+        contribs = res.contribs
+        for nr in range(numReps):                            # mcsas.py:434-437
+            for idx, param in enumerate(model.activeParams()):
+                param.setActiveVal(contribs[:, idx, nr].copy(), index=nr)
+        meas = res.fit.reshape(1, data.count, numReps)       # contribMeasVal, mcsas.py:210
+        ddof = 1 if numReps > 1 else 0
+        self.result.append(dict(
+            contribs=contribs,
+            fitMeasValMean=meas.mean(axis=2), fitMeasValStd=meas.std(axis=2),
+            fitX0=data.x0.binnedData, dataX0=data.x0.binnedData,
+            dataMean=data.f.binnedData, dataStd=data.f.binnedDataU,
+            scaling=(res.scaling.mean(), res.scaling.std(ddof=ddof)),
+            background=(res.background.mean(), res.background.std(ddof=ddof)),
+            times=res.seconds, numIter=res.num_iter.astype(float).mean()))
+
+    def histogram(self, contribs=None):                      # mcsas.py:445-615
+        if not isinstance(self.result, list) or not len(self.result):
+            logging.info("There are no results to histogram, breaking up.")
+            return
+        if contribs is None:
+            contribs = self.result[0]['contribs']
+        if not all(np.array(contribs.shape, dtype=bool)):
+            return
+        numContribs, dummy, numReps = contribs.shape
+        data, model = self.data, self.model
+        setup = setup_from_model(model, data)
+        c = self.compensationExponent()
+        vf = np.zeros((numContribs, numReps)); nf = np.zeros_like(vf); qf = np.zeros_like(vf); sf = np.zeros_like(vf)
+        vsets = np.zeros_like(vf); ssets = np.zeros_like(vf)
+        scalingFactors = np.zeros((2, numReps))
+        for ri in range(numReps):
+            cum, vset, wset, sset = engine.model_calc(setup, data.q, contribs[:, :, ri], c, device=self.device)   # :552
+            sc, conval, _ = engine.bgfit(data.f.binnedData, data.f.binnedDataU, cum, self.findBackground.value(),
+                                         self.positiveBackground.value(), setup.n_active, device=self.device)      # :559
+            scalingFactors[:, ri] = sc
+            vf[:, ri] = wset * sc[0] / vset                  # modeldata.py:57-61
+            nf[:, ri] = vf[:, ri] / vset
+            qf[:, ri] = vf[:, ri] * vset
+            sf[:, ri] = nf[:, ri] * sset
+            vsets[:, ri], ssets[:, ri] = vset, sset
+        # observability: N single-row model evaluations per rep (:575-590), one launch for all
+        sig = np.array(data.f.binnedDataU, dtype=float)
+        mv = engine.observability(setup, data.q, sig, contribs, scalingFactors[0], vf, c, device=self.device)
+        mn = mv / vsets                                      # :591-594
+        mq = mn * mv * mv
+        ms = mn * ssets
+        for ri in range(numReps):                            # :596-604
+            tn, tq, ts = sum(nf[:, ri]), sum(qf[:, ri]), sum(sf[:, ri])
+            if 0 != tn:
+                nf[:, ri] /= tn; mn[:, ri] /= tn
+            if 0 != tq:
+                qf[:, ri] /= tq; mq[:, ri] /= tq
+            if 0 != ts:
+                sf[:, ri] /= ts; ms[:, ri] /= ts
+        fractions = dict(vol=(vf, mv), num=(nf, mn), int=(qf, mq), surf=(sf, ms))
+        self.result[0]['scalingFactors'] = scalingFactors
+        self.fractions = fractions
+        for paramIndex, param in enumerate(model.activeParams()):
+            param.histograms().calc(contribs, paramIndex, fractions)

@@ -1,0 +1,211 @@
+"""Scattering-model plugins: host-side mirror of the reference's ScatteringModel / SASModel API
+(bases/model/scatteringmodel.py:14-127, bases/model/sasmodel.py:11-79, bases/model/modeldata.py)
+for the four models on the hot path.  A model here only *declares* its parameters; every
+evaluation (`calc`) runs in libmcsas_hip.so.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import engine
+from ..parameter import (Parameter, FitParameter, RandomUniform, RandomExponential, isActiveFitParam,
+                         generator_kind)
+
+NM = 1e-9
+SLD_A2 = 1e20          # Å⁻² -> m⁻²  (utils/units.py SLD)
+
+
+class SASModelData(object):
+    """bases/model/modeldata.py:4-64."""
+
+    def __init__(self, cumInt, vset, wset, sset, numParams):
+        self._cumInt = np.asarray(cumInt).flatten(); self._vset = np.asarray(vset).flatten()
+        self._wset = np.asarray(wset).flatten(); self._sset = np.asarray(sset).flatten()
+        self._numParams = abs(numParams)
+
+    cumInt = property(lambda self: self._cumInt)
+    chisqrInt = property(lambda self: self._cumInt)          # modeldata.py:19-24
+    vset = property(lambda self: self._vset)
+    wset = property(lambda self: self._wset)
+    sset = property(lambda self: self._sset)
+    numParams = property(lambda self: self._numParams)
+
+    def volumeFraction(self, scaling):                       # modeldata.py:57-61
+        return (self.wset * scaling / self.vset).flatten()
+
+
+class ScatteringModel(object):
+    """Declares `parameters` (a tuple of Parameter/FitParameter factories) like the reference's
+    model classes; instances get one attribute per parameter."""
+    shortName = None
+    model_id = None
+    parameters = ()
+
+    def __init__(self):
+        self._params = []
+        for make in self.parameters:
+            p = make()
+            setattr(self, p.name(), p)
+            self._params.append(p)
+
+    @classmethod
+    def name(cls):
+        return cls.shortName or cls.__name__
+
+    def params(self):
+        return tuple(self._params)
+
+    def paramCount(self):
+        return len(self._params)
+
+    def activeParams(self):
+        return tuple(p for p in self._params if isActiveFitParam(p))
+
+    def activeParamCount(self):
+        return len(self.activeParams())
+
+    def modelDataType(self):
+        return SASModelData
+
+    def getModelData(self, cumInt, vset, wset, sset):        # scatteringmodel.py:107-109
+        return self.modelDataType()(np.asarray(cumInt).flatten(), vset, wset, sset, self.activeParamCount())
+
+    def generateParameters(self, count=1):                   # scatteringmodel.py:117-127
+        lst = np.zeros((count, self.activeParamCount()))
+        for idx, param in enumerate(self.activeParams()):
+            lst[:, idx] = param.generate(count=count)
+        return lst
+
+    def setup(self, data=None) -> engine.ModelSetup:
+        return setup_from_model(self, data)
+
+    def calc(self, data, pset, compensationExponent=None):   # scatteringmodel.py:79-105, on the GPU
+        q = data.q if hasattr(data, "q") else np.asarray(data)
+        cum, v, w, s = engine.model_calc(self.setup(), q, pset, compensationExponent)
+        return self.getModelData(cum, v, w, s)
+
+
+class SASModel(ScatteringModel):
+    canSmear = False
+
+
+def _fp(*a, **k):
+    return lambda: FitParameter(*a, **k)
+
+
+def _p(*a, **k):
+    return lambda: Parameter(*a, **k)
+
+
+class Sphere(SASModel):
+    """models/sphere.py:12-65."""
+    shortName = "Sphere"
+    model_id = engine.MODEL_SPHERE
+    canSmear = True
+    parameters = (
+        _fp("radius", 10. * NM, displayName="Sphere radius", valueRange=(0., np.inf),
+            activeRange=(1. * NM, 1000. * NM), generator=RandomUniform),
+        _p("sld", 1e-6 * SLD_A2, displayName="scattering length density difference", valueRange=(0., np.inf)),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.radius.setActive(True)
+
+
+class CylindersIsotropic(SASModel):
+    """models/cylindersisotropic.py:17-103."""
+    shortName = "SASfit Isotropic Cylinders"
+    model_id = engine.MODEL_CYL_ISO
+    parameters = (
+        _fp("radius", 1. * NM, displayName="Cylinder Radius", generator=RandomExponential,
+            valueRange=(0.1 * NM, np.inf)),
+        _p("useAspect", True, displayName="Use aspect ratio (checked) or length "),
+        _fp("length", 10. * NM, displayName="Length L of the Cylinder", generator=RandomExponential,
+            valueRange=(0.1 * NM, 1e10 * NM)),
+        _fp("aspect", 10.0, displayName="Aspect ratio of the Cylinder", generator=RandomExponential,
+            valueRange=(1e-3, 1e3)),
+        _p("intDiv", 100., displayName="Orientation Integration Divisions", valueRange=(1, 1e4)),
+        _p("sld", 1e-6 * SLD_A2, displayName="Scattering length density difference", valueRange=(0, np.inf)),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.radius.setActive(True)
+
+
+class EllipsoidalCoreShell(SASModel):
+    """models/ellipsoidalcoreshell.py:14-99."""
+    shortName = "Core-Shell Ellipsoid"
+    model_id = engine.MODEL_ELL_CS
+    parameters = (
+        _fp("a", 1. * NM, displayName="Principal Core Radius", generator=RandomExponential,
+            valueRange=(0., np.inf), activeRange=(0.1 * NM, 1e3 * NM)),
+        _fp("b", 10. * NM, displayName="Equatorial Core Radius", generator=RandomExponential,
+            valueRange=(0., np.inf), activeRange=(1.0 * NM, 1e4 * NM)),
+        _fp("t", 1. * NM, displayName="Thickness of Shell", generator=RandomExponential,
+            valueRange=(0., np.inf), activeRange=(0.1 * NM, 1e3 * NM)),
+        _p("eta_c", 3.15e-6 * SLD_A2, displayName="Core SLD", valueRange=(0, np.inf)),
+        _p("eta_s", 2.53e-6 * SLD_A2, displayName="Shell SLD", valueRange=(0, np.inf)),
+        _p("eta_sol", 0., displayName="Solvent SLD", valueRange=(0, np.inf)),
+        _p("intDiv", 100, displayName="Orientation Integration Divisions", valueRange=(0, 1e4)),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.a.setActive(True)
+
+
+class Kholodenko(SASModel):
+    """models/kholodenko.py:51-96."""
+    shortName = "Kholodenko Worm"
+    model_id = engine.MODEL_KHOLODENKO
+    parameters = (
+        _fp("radius", 1. * NM, displayName="Radius", generator=RandomExponential,
+            valueRange=(0., np.inf), activeRange=(1 * NM, 5 * NM)),
+        _fp("lenKuhn", 1. * NM, displayName="kuhn length", generator=RandomUniform,
+            valueRange=(0., np.inf), activeRange=(10 * NM, 50 * NM)),
+        _fp("lenContour", 2. * NM, displayName="contour length", generator=RandomUniform,
+            valueRange=(0., np.inf), activeRange=(100 * NM, 1000 * NM)),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.radius.setActive(True)
+        self.lenKuhn.setActive(True)
+        self.lenContour.setActive(True)
+
+
+# reference class name -> kernel id (FindModels walks models/*.py, utils/findmodels.py:120-186)
+MODEL_IDS = {"Sphere": engine.MODEL_SPHERE, "CylindersIsotropic": engine.MODEL_CYL_ISO,
+             "EllipsoidalCoreShell": engine.MODEL_ELL_CS, "Kholodenko": engine.MODEL_KHOLODENKO}
+
+
+def setup_from_model(model, data=None) -> engine.ModelSetup:
+    """Flattens a configured model instance — ours or the reference's own (duck-typed through
+    params()/name()/value()/isActive()/activeRange()/valueRange()/generator()) — into the
+    ModelSetup the C ABI takes.  Unknown plugins have no device implementation: loud error."""
+    mid = getattr(model, "model_id", None)
+    if mid is None:
+        mid = MODEL_IDS.get(type(model).__name__)
+    if mid is None:
+        raise NotImplementedError("model %s has no HIP kernel (supported: %s)"
+                                  % (type(model).__name__, ", ".join(MODEL_IDS)))
+    params = list(model.params())
+    values = np.array([float(p()) for p in params], dtype=float)
+    active, lo, hi, kind, clo, chi, start = [], [], [], [], [], [], []
+    for i, p in enumerate(params):
+        if not isActiveFitParam(p):
+            continue
+        vr = p.valueRange()
+        ar = p.activeRange()
+        active.append(i)
+        lo.append(max(vr[0], min(ar))); hi.append(min(vr[1], max(ar)))     # parameter.py:66-84
+        kind.append(generator_kind(p.generator()))
+        clo.append(vr[0]); chi.append(vr[1])
+        mb = min(ar)                                                          # mcsas.py:311-315
+        if mb == 0 and data is not None:
+            mb = np.pi / data.x0.limit[1]
+        start.append(mb * .5)
+    return engine.ModelSetup(mid, values, tuple(active), np.array(lo), np.array(hi), tuple(kind),
+                             np.array(clo), np.array(chi), np.array(start))

@@ -1,0 +1,80 @@
+"""Shared by the test modules: fixture loading and building the SAME model configuration for the
+product (mcsas_amd) and for the checker (oracle)."""
+import os
+import numpy as np
+
+import mcsas_amd
+from mcsas_amd import engine
+from oracle import mcsas_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+CASES = {
+    "sphere": dict(cls=mcsas_amd.Sphere, omodel="sphere", active=["radius"]),
+    "cyl_aspect": dict(cls=mcsas_amd.CylindersIsotropic, omodel="cyl", active=["radius", "aspect"]),
+    "cyl_length": dict(cls=mcsas_amd.CylindersIsotropic, omodel="cyl", active=["radius", "length"],
+                       fixed=dict(useAspect=False)),
+    "ellcs": dict(cls=mcsas_amd.EllipsoidalCoreShell, omodel="ellcs", active=["a", "b", "t"]),
+    "kholodenko": dict(cls=mcsas_amd.Kholodenko, omodel="kholodenko", active=["radius", "lenKuhn", "lenContour"]),
+}
+GEN_CLS = {0: mcsas_amd.RandomUniform, 1: mcsas_amd.RandomExponential, 2: mcsas_amd.RandomExponential2,
+           3: mcsas_amd.RandomExponential3}
+
+
+def make_models(tag, lo=None, hi=None, gen=None, **fixed):
+    """-> (product model instance, oracle ModelSpec) configured identically."""
+    c = CASES[tag]
+    fx = dict(c.get("fixed", {})); fx.update(fixed)
+    m = c["cls"]()
+    for p in m.params():
+        if hasattr(p, "setActive"):
+            p.setActive(p.name() in c["active"])
+    for k, v in fx.items():
+        getattr(m, k).setValue(v)
+    n = len(c["active"])
+    for i, name in enumerate(c["active"]):
+        p = getattr(m, name)
+        if lo is not None:
+            p.setActiveRange((float(lo[i]), float(hi[i])))
+        if gen is not None:
+            p.setGenerator(GEN_CLS[int(gen[i])])
+    ofx = {k: float(v) for k, v in fx.items()}
+    spec = O.ModelSpec.make(c["omodel"], c["active"], lo if lo is not None else [0.0] * n,
+                            hi if hi is not None else [np.inf] * n, gen, **ofx)
+    return m, spec
+
+
+def traj_setup(name):
+    g = load(name)
+    model = str(g["spec_model"])
+    extra = {}
+    if model in ("sphere", "cyl_aspect"):
+        extra["sld"] = float(g["spec_sld"])
+    if model == "cyl_aspect":
+        extra["intDiv"] = float(g["spec_int_div"])
+    if model == "ellcs":
+        extra.update(eta_c=float(g["spec_eta_c"]), eta_s=float(g["spec_eta_s"]),
+                     eta_sol=float(g["spec_eta_sol"]), intDiv=float(g["spec_int_div"]))
+    m, spec = make_models(model, g["spec_lo"], g["spec_hi"], [int(x) for x in g["spec_gen"]], **extra)
+    flags = dict(find_bg=bool(int(g["spec_find_bg"])) if "spec_find_bg" in g else True,
+                 pos_bg=bool(int(g["spec_pos_bg"])) if "spec_pos_bg" in g else False,
+                 start_from_min=bool(int(g["spec_from_min"])) if "spec_from_min" in g else False)
+    ost = O.Settings(n_contrib=int(g["spec_n_contrib"]), n_reps=1, max_iter=int(g["spec_max_iter"]),
+                     comp_exp=float(g["spec_comp_exp"]), conv_crit=float(g["spec_conv_crit"]), **flags)
+    st = engine.Settings(n_contrib=ost.n_contrib, n_reps=1, max_iter=ost.max_iter, comp_exp=ost.comp_exp,
+                         conv_crit=ost.conv_crit, find_background=flags["find_bg"],
+                         positive_background=flags["pos_bg"], start_from_minimum=flags["start_from_min"],
+                         max_retries=0)
+    return g, m, spec, st, ost
+
+
+class FakeData(object):
+    """x0.limit holder for setup_from_model's startFromMinimum rule."""
+    def __init__(self, q):
+        class V: pass
+        self.x0 = V(); self.x0.limit = [float(np.min(q)), float(np.max(q))]
