@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py — MC accept/reject steps per second of the McSAS hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): Sphere model, synthetic 512 q-points x 400 contributions,
+50 repetitions per GPU, fixed Monte-Carlo budget per chain (convergenceCriterion = 0 so no chain
+leaves early; SURVEY §8d "throughput runs").  One bench "step" = one launch of all chains of the
+rank for `--mc-steps` MC iterations each, data and workspaces already resident in HBM.
+With --gpus N (one process per GPU, launched by torch.distributed.run) every rank runs its own
+50 reps (weak scaling) and one RCCL all-gather per step assembles the results.
+
+Prints ONE JSON line; see the module-level keys `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+Q, NCONTRIB, REPS_PER_GPU = 512, 400, 50
+HBM_PEAK = 8.0e12                     # B/s, MI355X_MICROARCH.md
+BYTES_PER_MC_STEP = 40 * Q            # read q, I, sigma, ft + write ft_test, fp64
+
+
+def synthetic_data(nq=Q, seed=20250101):
+    """q = logspace(1e7, 3e9) 1/m, tri-modal sphere population (8/40/100 nm),
+    sigma = 1 % of I, multiplicative Gaussian noise, flat background 0."""
+    q = np.logspace(7, np.log10(3e9), nq)
+    rs = np.random.RandomState(seed)
+    radii = np.abs(np.concatenate([rs.normal(8, 3, 300), rs.normal(40, 10, 150), rs.normal(100, 10, 50)])) + 0.5
+    radii *= 1e-9
+    I = np.zeros(nq)
+    for R in radii:
+        x = q * R
+        F = 3 * (np.sin(x) - x * np.cos(x)) / x**3
+        I += (4 * np.pi / 3 * R**3)**2 * F**2
+    I *= 1e3 / I.max()
+    sigma = 0.01 * I
+    I = I + sigma * rs.normal(size=nq)
+    return q, I, sigma
+
+
+def cpu_baseline(q, I, sigma, lo, hi, seconds_target=12.0):
+    """The CPU oracle (numpy restatement of mcFit, closed-form fit, cached rows) on ONE host core,
+    same workload shape, bounded sample."""
+    from oracle import mcsas_oracle as O
+    spec = O.ModelSpec.make("sphere", ["radius"], [lo], [hi])
+    probe = 400
+    st = O.Settings(n_contrib=NCONTRIB, n_reps=1, max_iter=probe, conv_crit=0.0)
+    t0 = time.time()
+    O.mc_fit(spec, q, I, sigma, [I.min(), I.max()], [q.min(), q.max()], st, O.PhiloxStream(1, 0), method="closed")
+    t_probe = time.time() - t0
+    steps = int(max(probe, min(200000, probe * seconds_target / max(t_probe, 1e-3))))
+    st.max_iter = steps
+    t0 = time.time()
+    r = O.mc_fit(spec, q, I, sigma, [I.min(), I.max()], [q.min(), q.max()], st, O.PhiloxStream(1, 0), method="closed")
+    dt = time.time() - t0
+    return {"value": r.num_iter / dt, "unit": "MC steps/s", "cores": 1, "kind": "port",
+            "sample": "1 chain x %d MC steps (incl. %d-contribution init), Sphere %dq x %d contribs, numpy oracle, 1 core"
+                      % (steps, NCONTRIB, Q, NCONTRIB)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mc-steps", type=int, default=20000, help="MC iterations per chain per launch")
+    ap.add_argument("--reps", type=int, default=REPS_PER_GPU, help="repetitions (chains) per GPU")
+    ap.add_argument("--waves", type=int, default=0, help="waves per chain (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import mcsas_amd
+    from mcsas_amd import engine, dist as mdist
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as tdist
+        tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    q, I, sigma = synthetic_data()
+    lo, hi = np.pi / q.max(), np.pi / q.min()
+    model = mcsas_amd.Sphere()
+    model.radius.setActiveRange((lo, hi))
+    n_total = args.reps * world
+    first = rank * args.reps
+    st = engine.Settings(n_contrib=NCONTRIB, n_reps=args.reps, max_iter=args.mc_steps, conv_crit=0.0,
+                         max_retries=0, seed=20250101, rep_offset=first, device=local_rank,
+                         waves_per_chain=args.waves)
+    plan = engine.Plan(model.setup(), q, I, sigma, st)
+
+    def one_step(seed):
+        plan.reseed(seed, first)
+        plan.launch()
+        res = plan.fetch()
+        if use_dist:
+            mdist.gather_results(dict(contribs=np.moveaxis(res.contribs, 2, 0), chisq=res.chisq[:, None],
+                                      scaling=res.scaling[:, None], background=res.background[:, None],
+                                      fit=res.fit.T), n_total)
+        return res
+
+    def barrier():
+        if use_dist:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        one_step(1000 + w)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms, mc_steps, res = 0.0, 0, None
+    for k in range(args.steps):
+        res = one_step(2000 + k)
+        kernel_ms += plan.last_ms
+        mc_steps += plan.total_steps
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt, float(mc_steps)], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
+        tsum = t.clone(); tdist.all_reduce(tsum, op=tdist.ReduceOp.SUM)
+        dt, total_steps = float(tmax[0]), float(tsum[1])
+    else:
+        total_steps = float(mc_steps)
+
+    if rank == 0:
+        launch_s = kernel_ms * 1e-3 / args.steps
+        achieved = BYTES_PER_MC_STEP * (mc_steps / args.steps) / launch_s
+        out = {
+            "metric": "MC accept/reject steps/sec (whole node)", "value": total_steps / dt, "unit": "MC steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Sphere, synthetic %d q-points x %d contribs, %d reps/GPU, %d MC steps per chain per launch, convergenceCriterion=0"
+                                   % (Q, NCONTRIB, args.reps, args.mc_steps),
+                       "reps_total": n_total, "waves_per_chain": plan.prob.c.waves_per_chain or 1},
+            "final_chisq_median": float(np.median(res.chisq)),
+            "kernel_ms_per_launch": launch_s * 1e3,
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "note": "achieved = 40*Q B per MC step (SURVEY 8d streaming model) x MC steps per launch / HIP-event kernel time"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(q, I, sigma, lo, hi)
+        print(json.dumps(out))
+    if use_dist:
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
