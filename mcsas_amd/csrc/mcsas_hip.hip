@@ -190,11 +190,22 @@ static void *wave_kernel_for(int model, int qpl, bool cache) {
         default: return nullptr;
     }
 }
-static void *wg_kernel_for(int model) {
+template <int M>
+static void *wg_kernel_for_qpl(int qpl) {
+    switch (qpl) {
+        case 1: return (void *)chain_wg_kernel<M, 1>;
+        case 2: return (void *)chain_wg_kernel<M, 2>;
+        case 4: return (void *)chain_wg_kernel<M, 4>;
+        case 8: return (void *)chain_wg_kernel<M, 8>;
+        case 16: return (void *)chain_wg_kernel<M, 16>;
+        default: return nullptr;
+    }
+}
+static void *wg_kernel_for(int model, int qpl) {
     switch (model) {
-        case MCSAS_MODEL_SPHERE: return (void *)chain_wg_kernel<MCSAS_MODEL_SPHERE>;
-        case MCSAS_MODEL_CYL_ISO: return (void *)chain_wg_kernel<MCSAS_MODEL_CYL_ISO>;
-        case MCSAS_MODEL_ELL_CS: return (void *)chain_wg_kernel<MCSAS_MODEL_ELL_CS>;
+        case MCSAS_MODEL_SPHERE: return wg_kernel_for_qpl<MCSAS_MODEL_SPHERE>(qpl);
+        case MCSAS_MODEL_CYL_ISO: return wg_kernel_for_qpl<MCSAS_MODEL_CYL_ISO>(qpl);
+        case MCSAS_MODEL_ELL_CS: return wg_kernel_for_qpl<MCSAS_MODEL_ELL_CS>(qpl);
         default: return nullptr;
     }
 }
@@ -278,7 +289,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     if (waves > 1) {
         int rcg = wg_geometry(p->nq, (int)N, table_doubles_host(p->model_id, margs.int_div), waves, &pl->wg);
         if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: problem does not fit LDS (nq=%d)", p->nq); }
-        cache_rows = (int)N + pl->wg.window;
+        cache_rows = (int)N + 2 * pl->wg.window;
     }
     size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
     int use_cache = p->cache_intensities;
@@ -351,7 +362,7 @@ extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
         fn = wave_kernel_for(pl->prob.model_id, pl->qpl, pl->use_cache);
         block = dim3(WAVE);
     } else {
-        fn = wg_kernel_for(pl->prob.model_id);
+        fn = wg_kernel_for(pl->prob.model_id, pl->qpl);
         block = dim3(WAVE * pl->waves);
     }
     if (pl->lds_bytes > 64 * 1024)

@@ -4,6 +4,7 @@
 // SASModel.calcIntensity()[0] (bases/model/sasmodel.py:46-79, smearing off).
 #pragma once
 #include "device_util.h"
+#include "fastmath.h"
 #include "../../include/mcsas_hip.h"
 
 namespace mcsas {
@@ -62,8 +63,8 @@ template <> struct Contrib<MCSAS_MODEL_SPHERE> {
     }
     __device__ __forceinline__ double intensity(double q, const double *) const {
         double x = q * r, sn, cs;
-        sincos(x, &sn, &cs);
-        double f = 3. * (sn - x * cs) / (x * x * x);  // sphere.py:62
+        sincos_fast(x, &sn, &cs);
+        double f = div_fast(3. * (sn - x * cs), x * x * x);  // sphere.py:62
         return f * f * w;
     }
 };
@@ -166,11 +167,11 @@ template <> struct Contrib<MCSAS_MODEL_ELL_CS> {
             double xc = q * sqrt(a2 * m2 + b2 * n2);
             double xt = q * sqrt(at2 * m2 + bt2 * n2);
             double sc, cc, st, ct;
-            sincos(xc, &sc, &cc);
-            sincos(xt, &st, &ct);
-            double jc = (sc - xc * cc) / (xc * xc);
-            double jt = (st - xt * ct) / (xt * xt);
-            double f = c1 * (3. * jc / xc) + c2 * (3. * jt / xt);
+            sincos_fast(xc, &sc, &cc);
+            sincos_fast(xt, &st, &ct);
+            double jc = div_fast(sc - xc * cc, xc * xc);
+            double jt = div_fast(st - xt * ct, xt * xt);
+            double f = c1 * div_fast(3. * jc, xc) + c2 * div_fast(3. * jt, xt);
             acc += f * f;
         }
         double ff = sqrt(acc * invK);     // numpy.sqrt(numpy.mean(fsplit**2, axis=1))
