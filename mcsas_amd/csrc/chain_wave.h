@@ -18,8 +18,12 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(const ChainArgs a) {
     const int lane = threadIdx.x;
     const int rep = blockIdx.x;
     const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad;
-    double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *tab = lds + 3 * qpad;
-    for (int i = lane; i < qpad; i += WAVE) { lq[i] = a.q[i]; lw[i] = a.w[i]; lwI[i] = a.wI[i]; }
+    double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
+    for (int i = lane; i < qpad; i += WAVE) {
+        const double qq = a.q[i];
+        lq[i] = qq; lw[i] = a.w[i]; lwI[i] = a.wI[i]; lq3[i] = 1.0 / (qq * qq * qq);
+    }
+    const QTables qt{lq, lq3, tab};
     Contrib<M>::fill_table(a.model, tab, lane, WAVE);
     __syncthreads();
 
@@ -66,11 +70,12 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(const ChainArgs a) {
             const int cnt = min(WAVE, N - n0);
             for (int i = 0; i < cnt; ++i) {
                 const Contrib<M> c = mine.bcast(__builtin_amdgcn_readfirstlane(i));
+                double it[QPL];
+                RowEval<M, QPL>::run(c, qt, lane, it);
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
-                    double it = c.intensity(lq[lane + WAVE * j], tab);
-                    ft[j] += it;
-                    if (CACHE) cache[(size_t)(n0 + i) * qpad + lane + WAVE * j] = it;
+                    ft[j] += it[j];
+                    if (CACHE) cache[(size_t)(n0 + i) * qpad + lane + WAVE * j] = it[j];
                 }
             }
         }
@@ -130,13 +135,12 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(const ChainArgs a) {
                     for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) orow[p] = (p < P) ? rset[(size_t)ri * P + p] : 0.;
                     Contrib<M> cold;
                     cold.prepare(a.model, orow);
-#pragma unroll
-                    for (int j = 0; j < QPL; ++j) test[j] = cold.intensity(lq[lane + WAVE * j], tab);
+                    RowEval<M, QPL>::run(cold, qt, lane, test);
                 }
                 double s1 = 0., s2 = 0., s3 = 0.;
+                RowEval<M, QPL>::run(cnew, qt, lane, inew);
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
-                    inew[j] = cnew.intensity(lq[lane + WAVE * j], tab);
                     test[j] = (ft[j] - test[j]) + inew[j];                         // mcsas.py:367
                     double wt = lw[lane + WAVE * j] * test[j];
                     s1 += wt; s2 += wt * test[j]; s3 += lwI[lane + WAVE * j] * test[j];

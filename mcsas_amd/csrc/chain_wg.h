@@ -30,7 +30,7 @@ namespace mcsas {
 
 struct WgGeom {
     int32_t waves, window, qpl, tab_doubles;
-    int32_t off_tab, off_ft, off_wft, off_drow, off_scal, off_pval, off_ints;   // in doubles from the LDS base
+    int32_t off_q3, off_tab, off_ft, off_wft, off_drow, off_scal, off_pval, off_ints;   // in doubles from the LDS base
     int32_t n_contrib;
     uint64_t lds_bytes;
 };
@@ -47,8 +47,8 @@ static inline int wg_geometry(int nq, int n_contrib, int tab_doubles, int waves,
     for (int mult = 8; mult >= 1; --mult) {
         int K = np * mult;
         if (2 * K > n_contrib || K > 64) continue;
-        size_t dbl = 3 * (size_t)qpad + tab_doubles;          // q, w, wI, table
-        g->off_tab = 3 * qpad;
+        size_t dbl = 4 * (size_t)qpad + tab_doubles;          // q, w, wI, 1/q^3, table
+        g->off_q3 = 3 * qpad; g->off_tab = 4 * qpad;
         g->off_ft = (int32_t)dbl; dbl += qpad;                // the scanner's ft
         g->off_wft = (int32_t)dbl; dbl += qpad;               // and w*ft
         g->off_drow = (int32_t)dbl; dbl += 2 * (size_t)K * qpad;
@@ -71,13 +71,13 @@ static inline int wg_geometry(int nq, int n_contrib, int tab_doubles, int waves,
 enum { CTL_DONE = 0, CTL_NUM_ITER = 2, CTL_FINISHED = 4, CTL_OVF = 5, CTL_COUNT = 16 };
 
 struct WgShared {
-    double *lq, *lw, *lwI, *tab, *lft, *lwft, *drow, *scal, *pval;
+    double *lq, *lw, *lwI, *lq3, *tab, *lft, *lwft, *drow, *scal, *pval;
     int32_t *ctl, *stage_slot, *povf, *slot_of;
 };
 
 __device__ __forceinline__ WgShared wg_carve(double *lds, const WgGeom &g, int qpad) {
     WgShared s;
-    s.lq = lds; s.lw = lds + qpad; s.lwI = lds + 2 * qpad; s.tab = lds + g.off_tab;
+    s.lq = lds; s.lw = lds + qpad; s.lwI = lds + 2 * qpad; s.lq3 = lds + g.off_q3; s.tab = lds + g.off_tab;
     s.lft = lds + g.off_ft; s.lwft = lds + g.off_wft;
     s.drow = lds + g.off_drow; s.scal = lds + g.off_scal; s.pval = lds + g.off_pval;
     s.ctl = reinterpret_cast<int32_t *>(lds + g.off_ints);
@@ -119,9 +119,10 @@ __device__ __forceinline__ void wg_init_rows(const ChainArgs &a, const WgGeom &g
             const int nn = nb + l * W + wave;
             if (nn >= N) break;
             const Contrib<M> c = mine.bcast(__builtin_amdgcn_readfirstlane(l));
+            double it[QPL];
+            RowEval<M, QPL>::run(c, QTables{sh.lq, sh.lq3, sh.tab}, lane, it);
 #pragma unroll
-            for (int j = 0; j < QPL; ++j)
-                cache[(size_t)nn * qpad + lane + WAVE * j] = c.intensity(sh.lq[lane + WAVE * j], sh.tab);
+            for (int j = 0; j < QPL; ++j) cache[(size_t)nn * qpad + lane + WAVE * j] = it[j];
         }
     }
     if (__any(ovf_init) && lane == 0) atomicOr(&sh.ctl[CTL_OVF], 1);
@@ -157,7 +158,7 @@ __device__ __forceinline__ void wg_producer(const ChainArgs &a, const WgGeom &g,
         int pov = 0;
         for (int64_t win = 0;; ++win) {
             const int buf = (int)(win & 1);
-            if (chain_runs) {
+            if (chain_runs && !(a.pad0 & 1)) {
                 for (int jj = 0; jj < rpw; ++jj) {
                     const int k = (wave - 1) + NP * jj;
                     const int64_t s = win * K + k;
@@ -184,14 +185,15 @@ __device__ __forceinline__ void wg_producer(const ChainArgs &a, const WgGeom &g,
                     const double *orow = cache + (size_t)oslot * qpad + lane;
                     double *nrow = cache + (size_t)sslot * qpad + lane;
                     double *dr = sh.drow + ((size_t)buf * K + k) * qpad + lane;
-                    double d[QPL];
+                    double d[QPL], nwv[QPL];
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) d[j] = orow[WAVE * j];
+                    RowEval<M, QPL>::run(cnew, QTables{sh.lq, sh.lq3, sh.tab}, lane, nwv);
                     double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {
                         const int i = lane + WAVE * j;
-                        const double nw = cnew.intensity(sh.lq[i], sh.tab);
+                        const double nw = nwv[j];
                         nrow[WAVE * j] = nw;
                         d[j] = nw - d[j];
                         dr[WAVE * j] = d[j];
@@ -294,6 +296,7 @@ __device__ __forceinline__ void wg_scanner(const ChainArgs &a, const WgGeom &g, 
                 const double *sbase = sh.scal + (size_t)sb * K * 4;
                 int k = 0;
                 if (!(cur.chi2 > a.conv_crit) || stopped) k = kmax;      // nothing to do
+                if (a.pad0 & 2) { num_iter += kmax - k; k = kmax; }       // diagnostic: skip the scan
                 for (; k < kmax; ++k) {
                     const double *dr = dbase + (size_t)k * qpad;
                     double dl[QPL], h0 = 0., h1 = 0.;
@@ -316,11 +319,14 @@ __device__ __forceinline__ void wg_scanner(const ChainArgs &a, const WgGeom &g, 
                     }
                     if (sh.povf[sb * K + k]) overflow = 1;
                     if (num * num > (S - X) * den) {                       // chi²_t < chi²  (mcsas.py:379)
+                        double fo[QPL], wv[QPL];
+#pragma unroll
+                        for (int j = 0; j < QPL; ++j) { fo[j] = lft[WAVE * j]; wv[j] = sh.lw[lane + WAVE * j]; }
 #pragma unroll
                         for (int j = 0; j < QPL; ++j) {
-                            const double f = lft[WAVE * j] + dl[j];
+                            const double f = fo[j] + dl[j];
                             lft[WAVE * j] = f;
-                            lwft[WAVE * j] = sh.lw[lane + WAVE * j] * f;
+                            lwft[WAVE * j] = wv[j] * f;
                         }
                         SC = SCt; SIC = SICt; SCC = SCCt;
                         cur = solve_fit(a, SC, SCC, SIC);
@@ -411,7 +417,10 @@ __global__ __launch_bounds__(WG_MAX_WAVES * 64) void chain_wg_kernel(const Chain
     const int tid = threadIdx.x;
     const WgShared sh = wg_carve(lds, g, a.qpad);
     const int T = g.waves * WAVE;
-    for (int i = tid; i < a.qpad; i += T) { sh.lq[i] = a.q[i]; sh.lw[i] = a.w[i]; sh.lwI[i] = a.wI[i]; }
+    for (int i = tid; i < a.qpad; i += T) {
+        const double qq = a.q[i];
+        sh.lq[i] = qq; sh.lw[i] = a.w[i]; sh.lwI[i] = a.wI[i]; sh.lq3[i] = 1.0 / (qq * qq * qq);
+    }
     Contrib<M>::fill_table(a.model, sh.tab, tid, T);
     // (the first barrier of either role publishes the tables)
     if ((tid >> 6) == 0) wg_scanner<M, QPL>(a, g, sh, blockIdx.x);

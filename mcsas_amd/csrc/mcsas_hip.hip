@@ -134,6 +134,8 @@ static int fill_model_args(const mcsas_problem *p, ModelArgs *m) {
             return fail(MCSAS_EINVAL, "active_index[%d]=%d out of range", c, p->active_index[c]);
     }
     m->int_div = model_int_div(p);
+    m->qmax = 0.;
+    if (p->q) for (int i = 0; i < p->nq; ++i) m->qmax = std::max(m->qmax, std::fabs(p->q[i]));
     if (p->model_id != MCSAS_MODEL_SPHERE && (m->int_div < 2 || m->int_div > 4096))
         return fail(MCSAS_EINVAL, "intDiv %d unsupported (2..4096)", m->int_div);
     return MCSAS_OK;
@@ -327,13 +329,13 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         a.gen_lo[c] = p->gen_lo[c]; a.gen_hi[c] = p->gen_hi[c]; a.start_value[c] = p->start_value[c];
         a.gen_kind[c] = p->gen_kind[c];
     }
-    a.seed = p->seed; a.rep_offset = p->rep_offset;
+    a.seed = p->seed; a.rep_offset = p->rep_offset; a.pad0 = p->reserved0;   // reserved0: diagnostic role ablation
     a.replay = pl->d_replay; a.replay_len = p->replay_len;
     a.stop_flag = d_stop;
     a.rset = pl->d_rset; a.cache = pl->d_cache; a.cache_rows = cache_rows; a.fit = pl->d_fit; a.out = pl->d_out;
 
     if (waves == 1) {
-        pl->lds_bytes = sizeof(double) * (3 * (size_t)qpad + table_doubles_host(p->model_id, margs.int_div));
+        pl->lds_bytes = sizeof(double) * (4 * (size_t)qpad + table_doubles_host(p->model_id, margs.int_div));
         if (!wave_kernel_for(p->model_id, qpl, use_cache)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no kernel for model %d qpl %d", p->model_id, qpl); }
     } else {
         pl->lds_bytes = pl->wg.lds_bytes;

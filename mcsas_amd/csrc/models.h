@@ -20,6 +20,14 @@ struct ModelArgs {
     double  comp_exp;
     int32_t int_div;       // orientation / quadrature points K (1 for the sphere)
     int32_t pad;
+    double  qmax;          // largest q of the data set: bounds q*R for the branch-free sincos
+};
+
+// read-only per-block tables in LDS
+struct QTables {
+    const double *q;       // [qpad]
+    const double *q3inv;   // [qpad] 1/q^3
+    const double *tab;     // orientation table of the model
 };
 
 // full parameter vector for one contribution: active columns from `row`, clipped into their
@@ -44,7 +52,8 @@ template <int M> struct Contrib;
 // ---------------------------------------------------------------------------------- Sphere
 // models/sphere.py:32-63
 template <> struct Contrib<MCSAS_MODEL_SPHERE> {
-    double r, v, w, s;
+    double r, v, w, s, invr3;
+    int fast;              // q*r < 2^20 for every q of the data set: branch-free sincos is valid
     static __device__ __forceinline__ int table_doubles(int) { return 0; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
     __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
@@ -55,11 +64,21 @@ template <> struct Contrib<MCSAS_MODEL_SPHERE> {
         v = vol * (p[1] * p[1]);                      // sphere.py:53
         s = 4. * PI * r * r;                          // sphere.py:37
         w = pow(vol, 2. * a.comp_exp);                // sasmodel.py:44
+        invr3 = 1.0 / (r * r * r);
+        fast = (a.qmax * r < 1048576.0) && (r > 0.);
     }
     // copy of lane `lane`'s contribution into wave-uniform registers
     __device__ __forceinline__ Contrib bcast(int lane) const {
         Contrib o; o.r = readlane_f64(r, lane); o.w = readlane_f64(w, lane); o.v = 0.; o.s = 0.;
+        o.invr3 = readlane_f64(invr3, lane); o.fast = __builtin_amdgcn_readlane(fast, lane);
         return o;
+    }
+    // branch-free evaluation, valid when `fast`: 1/x^3 from the two precomputed reciprocals
+    __device__ __forceinline__ double intensity_fast(double q, double q3inv) const {
+        double x = q * r, sn, cs;
+        sincos_core(x, &sn, &cs);
+        double f = (3. * (sn - x * cs)) * (q3inv * invr3);
+        return f * f * w;
     }
     __device__ __forceinline__ double intensity(double q, const double *) const {
         double x = q * r, sn, cs;
@@ -176,6 +195,28 @@ template <> struct Contrib<MCSAS_MODEL_ELL_CS> {
         }
         double ff = sqrt(acc * invK);     // numpy.sqrt(numpy.mean(fsplit**2, axis=1))
         return ff * ff * w;
+    }
+};
+
+// ---------------------------------------------------------------------------------- row evaluation
+// out[j] = I(q[lane + 64 j]) for one contribution; the wave-uniform fast/slow choice is made once
+// per row so the QPL evaluations stay in one basic block and interleave.
+template <int M, int QPL> struct RowEval {
+    static __device__ __forceinline__ void run(const Contrib<M> &c, const QTables &t, int lane, double (&out)[QPL]) {
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) out[j] = c.intensity(t.q[lane + WAVE * j], t.tab);
+    }
+};
+template <int QPL> struct RowEval<MCSAS_MODEL_SPHERE, QPL> {
+    static __device__ __forceinline__ void run(const Contrib<MCSAS_MODEL_SPHERE> &c, const QTables &t, int lane,
+                                               double (&out)[QPL]) {
+        if (c.fast) {
+#pragma unroll
+            for (int j = 0; j < QPL; ++j) out[j] = c.intensity_fast(t.q[lane + WAVE * j], t.q3inv[lane + WAVE * j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < QPL; ++j) out[j] = c.intensity(t.q[lane + WAVE * j], t.tab);
+        }
     }
 };
 

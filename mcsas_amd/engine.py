@@ -57,6 +57,7 @@ class Settings:
     device: int = -1
     waves_per_chain: int = 0
     cache_intensities: int = -1
+    debug_flags: int = 0               # diagnostic only (role ablation in the workgroup kernel)
 
 
 def _fill(arr, values, n):
@@ -97,6 +98,7 @@ class HipProblem:
         p.start_from_minimum = int(bool(st.start_from_minimum))
         p.seed = int(st.seed) & 0xFFFFFFFFFFFFFFFF
         p.rep_offset = int(st.rep_offset)
+        p.reserved0 = int(st.debug_flags)
         self.replay = None
         if replay is not None:
             self.replay = f64(replay).reshape(p.n_reps, -1)

@@ -1,0 +1,106 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol include/mcsas_hip.h
+declares, the ctypes structs match the C layout, and the host-side mirror of the reference's
+plugin API flattens models the way the kernels expect."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import mcsas_amd
+from mcsas_amd import _lib, engine
+from mcsas_amd.scatteringmodels import setup_from_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mcsas_hip.h")
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()                                   # raises if the .so is missing: no fallback
+    text = open(HEADER).read()
+    declared = set(re.findall(r"\b(mcsas_hip_[a-z_0-9]+)\s*\(", text))
+    assert declared == set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.mcsas_hip_abi_version() == _lib.ABI_VERSION
+    assert lib.mcsas_hip_device_count() >= 0            # 0 here: no GPU in the build container
+
+
+def test_struct_layout_matches_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\n'
+                   'int main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(mcsas_problem), sizeof(mcsas_result),'
+                   ' offsetof(mcsas_problem, n_contrib), offsetof(mcsas_problem, seed), offsetof(mcsas_problem, stop),'
+                   ' offsetof(mcsas_result, draws)); return 0;}\n' % HEADER)
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-o", str(exe), str(src)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == C.sizeof(_lib.Problem) and out[1] == C.sizeof(_lib.Result)
+    assert out[2] == _lib.Problem.n_contrib.offset and out[3] == _lib.Problem.seed.offset
+    assert out[4] == _lib.Problem.stop.offset and out[5] == _lib.Result.draws.offset
+
+
+def test_errors_without_gpu_are_loud():
+    """No device in this container: the product path reports MCSAS_ENODEV, it does not fall back."""
+    if _lib.load().mcsas_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    m = mcsas_amd.Sphere()
+    with pytest.raises(_lib.McSASHipError) as e:
+        engine.analyse(m.setup(), np.logspace(7, 9, 16), np.ones(16), np.ones(16),
+                       engine.Settings(n_contrib=4, n_reps=1, max_iter=1))
+    assert e.value.code == -2
+
+
+def test_model_flattening_follows_reference_rules():
+    m = mcsas_amd.CylindersIsotropic()
+    m.radius.setActive(True); m.aspect.setActive(True)
+    m.radius.setActiveRange((1e-12, 5e-8))            # below valueRange min 0.1 nm -> clipped (utils/parameter.py:615-624)
+    m.aspect.setActiveRange((20.0, 0.5))              # reversed -> (min, max)
+    s = m.setup()
+    assert s.model_id == engine.MODEL_CYL_ISO
+    assert s.active_index == (0, 3)                    # radius, aspect in `parameters` order
+    np.testing.assert_allclose(s.gen_lo, [1e-10, 0.5]); np.testing.assert_allclose(s.gen_hi, [5e-8, 20.0])
+    assert s.gen_kind == (1, 1)                        # RandomExponential
+    np.testing.assert_allclose(s.clip_lo, [1e-10, 1e-3])
+    assert s.params[1] == 1.0 and s.params[4] == 100.0
+    m.useAspect.setValue(False)
+    assert m.setup().params[1] == 0.0
+    k = mcsas_amd.Kholodenko().setup()
+    assert k.active_index == (0, 1, 2) and k.gen_kind == (1, 0, 0)
+    # startFromMinimum fill: min(activeRange)/2, or pi/qmax/2 when the range starts at 0 (mcsas.py:311-315)
+    sp = mcsas_amd.Sphere(); sp.radius.setActiveRange((0.0, 1e-7))
+    class D: pass
+    d = D(); d.x0 = D(); d.x0.limit = [1e7, 2e9]
+    np.testing.assert_allclose(setup_from_model(sp, d).start_value, [np.pi / 2e9 * .5])
+    class Foreign: pass
+    with pytest.raises(NotImplementedError):
+        setup_from_model(Foreign())
+
+
+def test_parameter_api_mirrors_reference_semantics():
+    p = mcsas_amd.Sphere().radius
+    p.setValue(-1.0)
+    assert p() == 0.0                                   # clipped into valueRange (parameter.py:405-414)
+    p.setActive(False); p.setActiveVal(np.ones(3), index=0)
+    assert p.activeValues() == []                       # inactive parameters ignore setActiveVal
+    p.setActive(True); p.setActiveVal(np.ones(3), index=2)
+    assert len(p.activeValues()) == 3 and p.activeValues()[0] is None
+    np.random.seed(3)
+    u = np.random.uniform(size=5)
+    np.random.seed(3)
+    p.setActiveRange((2e-9, 4e-9))
+    np.testing.assert_allclose(p.generate(count=5), u * 2e-9 + 2e-9)
+    algo = mcsas_amd.McSAS.factory()()
+    assert algo.numContribs() == 300 and algo.compensationExponent() == 0.6666666 and algo.maxRetries() == 5
+    algo.maxRetries.setValue(500)
+    assert algo.maxRetries() == 100                     # mcsasparameters.json valueRange [1, 100]
+    algo.stop = True
+    assert algo.stop is True
+
+
+def test_sasdata_from_reference_csv(golden_dir):
+    d = mcsas_amd.SASData.fromCsv(os.path.join(golden_dir, "ref_testdata", "quickstartdemo1.csv"))
+    assert d.count == 101 and abs(d.q[0] - 1e7) < 1 and d.f.binnedDataU[0] == 1.89e8
+    np.testing.assert_allclose(d.sphericalSizeEst(), [np.pi / 1e9, np.pi / 1e7])

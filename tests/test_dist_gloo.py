@@ -1,0 +1,57 @@
+"""Multi-process layout of McSAS.analyse on CPU: world_size-2 gloo run of the rep sharding and the
+single end-of-run all-gather (mcsas_amd/dist.py).  The per-rep payload is synthetic here (no GPU);
+what is checked is that every rank ends up with all reps in rep order."""
+import os
+import socket
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mcsas_amd.dist import shard_reps, gather_results
+
+
+def test_shard_reps_partitions_in_order():
+    for R, W in ((50, 8), (7, 2), (3, 4), (400, 8), (1, 1)):
+        blocks = [shard_reps(R, W, r) for r in range(W)]
+        assert sum(c for _, c in blocks) == R
+        pos = 0
+        for first, count in blocks:
+            assert first == pos
+            pos += count
+        assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+
+
+def _fake_rep(r, N, P, Q):
+    rs = np.random.RandomState(1000 + r)
+    return dict(contribs=rs.rand(N, P), fit=rs.rand(Q), chisq=np.array([float(r) + 0.5]))
+
+
+def _worker(rank, world, port, R, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, P, Q = 6, 2, 5
+    first, count = shard_reps(R, world, rank)
+    reps = [_fake_rep(first + i, N, P, Q) for i in range(count)]
+    local = {k: np.stack([x[k] for x in reps]) if count else np.zeros((0,) + _fake_rep(0, N, P, Q)[k].shape)
+             for k in ("contribs", "fit", "chisq")}
+    full = gather_results(local, R)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **full)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R", [5, 4])
+def test_two_rank_gather_restores_rep_order(tmp_path, R):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, R, str(tmp_path)), nprocs=2, join=True)
+    want = [_fake_rep(r, 6, 2, 5) for r in range(R)]
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        for k in ("contribs", "fit", "chisq"):
+            np.testing.assert_array_equal(got[k], np.stack([w[k] for w in want]))
+
+
+def test_single_process_is_a_passthrough():
+    out = gather_results(dict(a=np.arange(6.0).reshape(3, 2)), 3)
+    np.testing.assert_array_equal(out["a"], np.arange(6.0).reshape(3, 2))
