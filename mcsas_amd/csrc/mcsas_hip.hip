@@ -13,8 +13,8 @@
 #include <vector>
 
 #include "../../include/mcsas_hip.h"
-#include "chain_wave.h"
-#include "chain_wg.h"
+#include "chain_common.h"
+#include "chain_wg.h"   // WgGeom / wg_geometry only; the kernels are instantiated in kern_*.hip
 
 using namespace mcsas;
 
@@ -122,7 +122,6 @@ static int model_int_div(const mcsas_problem *p) {
 
 static int fill_model_args(const mcsas_problem *p, ModelArgs *m) {
     if (p->model_id < 0 || p->model_id >= MCSAS_MODEL_COUNT) return fail(MCSAS_EINVAL, "unknown model_id %d", p->model_id);
-    if (p->model_id == MCSAS_MODEL_KHOLODENKO) return fail(MCSAS_EINVAL, "Kholodenko model: kernel not built yet");
     if (p->n_active < 1 || p->n_active > MCSAS_MAX_ACTIVE) return fail(MCSAS_EINVAL, "n_active %d out of range", p->n_active);
     memset(m, 0, sizeof *m);
     m->model_id = p->model_id; m->n_active = p->n_active; m->comp_exp = p->comp_exp;
@@ -136,12 +135,16 @@ static int fill_model_args(const mcsas_problem *p, ModelArgs *m) {
     m->int_div = model_int_div(p);
     m->qmax = 0.;
     if (p->q) for (int i = 0; i < p->nq; ++i) m->qmax = std::max(m->qmax, std::fabs(p->q[i]));
-    if (p->model_id != MCSAS_MODEL_SPHERE && (m->int_div < 2 || m->int_div > 4096))
+    if ((p->model_id == MCSAS_MODEL_CYL_ISO || p->model_id == MCSAS_MODEL_ELL_CS) && (m->int_div < 2 || m->int_div > 4096))
         return fail(MCSAS_EINVAL, "intDiv %d unsupported (2..4096)", m->int_div);
     return MCSAS_OK;
 }
 
-static int table_doubles_host(int model_id, int K) { return model_id == MCSAS_MODEL_SPHERE ? 0 : 2 * K; }
+static int table_doubles_host(int model_id, int K) {
+    if (model_id == MCSAS_MODEL_SPHERE) return 0;
+    if (model_id == MCSAS_MODEL_KHOLODENKO) return 32;
+    return 2 * K;
+}
 
 static int select_device(int device) {
     int n = 0;
@@ -169,45 +172,26 @@ struct mcsas_plan {
     WgGeom wg{};
 };
 
-template <int M, int QPL>
-static void *wave_kernel_ptr(bool cache) {
-    return cache ? (void *)chain_wave_kernel<M, QPL, true> : (void *)chain_wave_kernel<M, QPL, false>;
-}
-template <int M>
-static void *wave_kernel_for_qpl(int qpl, bool cache) {
-    switch (qpl) {
-        case 1: return wave_kernel_ptr<M, 1>(cache);
-        case 2: return wave_kernel_ptr<M, 2>(cache);
-        case 4: return wave_kernel_ptr<M, 4>(cache);
-        case 8: return wave_kernel_ptr<M, 8>(cache);
-        case 16: return wave_kernel_ptr<M, 16>(cache);
-        default: return nullptr;
-    }
-}
+// kernel lookups, one translation unit per model (kern_wave.hip / kern_wg.hip)
+void *mcsas_wave_kernel_m0(int, bool); void *mcsas_wave_kernel_m1(int, bool);
+void *mcsas_wave_kernel_m2(int, bool); void *mcsas_wave_kernel_m3(int, bool);
+void *mcsas_wg_kernel_m0(int); void *mcsas_wg_kernel_m1(int); void *mcsas_wg_kernel_m2(int); void *mcsas_wg_kernel_m3(int);
+
 static void *wave_kernel_for(int model, int qpl, bool cache) {
     switch (model) {
-        case MCSAS_MODEL_SPHERE: return wave_kernel_for_qpl<MCSAS_MODEL_SPHERE>(qpl, cache);
-        case MCSAS_MODEL_CYL_ISO: return wave_kernel_for_qpl<MCSAS_MODEL_CYL_ISO>(qpl, cache);
-        case MCSAS_MODEL_ELL_CS: return wave_kernel_for_qpl<MCSAS_MODEL_ELL_CS>(qpl, cache);
-        default: return nullptr;
-    }
-}
-template <int M>
-static void *wg_kernel_for_qpl(int qpl) {
-    switch (qpl) {
-        case 1: return (void *)chain_wg_kernel<M, 1>;
-        case 2: return (void *)chain_wg_kernel<M, 2>;
-        case 4: return (void *)chain_wg_kernel<M, 4>;
-        case 8: return (void *)chain_wg_kernel<M, 8>;
-        case 16: return (void *)chain_wg_kernel<M, 16>;
+        case MCSAS_MODEL_SPHERE: return mcsas_wave_kernel_m0(qpl, cache);
+        case MCSAS_MODEL_CYL_ISO: return mcsas_wave_kernel_m1(qpl, cache);
+        case MCSAS_MODEL_ELL_CS: return mcsas_wave_kernel_m2(qpl, cache);
+        case MCSAS_MODEL_KHOLODENKO: return mcsas_wave_kernel_m3(qpl, cache);
         default: return nullptr;
     }
 }
 static void *wg_kernel_for(int model, int qpl) {
     switch (model) {
-        case MCSAS_MODEL_SPHERE: return wg_kernel_for_qpl<MCSAS_MODEL_SPHERE>(qpl);
-        case MCSAS_MODEL_CYL_ISO: return wg_kernel_for_qpl<MCSAS_MODEL_CYL_ISO>(qpl);
-        case MCSAS_MODEL_ELL_CS: return wg_kernel_for_qpl<MCSAS_MODEL_ELL_CS>(qpl);
+        case MCSAS_MODEL_SPHERE: return mcsas_wg_kernel_m0(qpl);
+        case MCSAS_MODEL_CYL_ISO: return mcsas_wg_kernel_m1(qpl);
+        case MCSAS_MODEL_ELL_CS: return mcsas_wg_kernel_m2(qpl);
+        case MCSAS_MODEL_KHOLODENKO: return mcsas_wg_kernel_m3(qpl);
         default: return nullptr;
     }
 }
@@ -486,6 +470,8 @@ extern "C" int mcsas_hip_model_calc(const mcsas_problem *p, const double *pset, 
             model_rows_kernel<MCSAS_MODEL_CYL_ISO><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
         case MCSAS_MODEL_ELL_CS:
             model_rows_kernel<MCSAS_MODEL_ELL_CS><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
+        case MCSAS_MODEL_KHOLODENKO:
+            model_rows_kernel<MCSAS_MODEL_KHOLODENKO><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
         default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
     }
     HIPCHK(hipGetLastError());
@@ -542,6 +528,8 @@ extern "C" int mcsas_hip_observability(const mcsas_problem *p, const double *con
             observability_kernel<MCSAS_MODEL_CYL_ISO><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
         case MCSAS_MODEL_ELL_CS:
             observability_kernel<MCSAS_MODEL_ELL_CS><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
+        case MCSAS_MODEL_KHOLODENKO:
+            observability_kernel<MCSAS_MODEL_KHOLODENKO><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
         default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
     }
     HIPCHK(hipGetLastError());
