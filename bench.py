@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--mc-steps", type=int, default=20000, help="MC iterations per chain per launch")
     ap.add_argument("--reps", type=int, default=REPS_PER_GPU, help="repetitions (chains) per GPU")
     ap.add_argument("--waves", type=int, default=0, help="waves per chain (0 = library default)")
+    ap.add_argument("--mode", type=int, default=0, help="exec_mode: 0 auto, 1 wave, 2 workgroup, 3 pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic role ablation (invalid results)")
     args = ap.parse_args()
@@ -98,7 +99,7 @@ def main():
     first = rank * args.reps
     st = engine.Settings(n_contrib=NCONTRIB, n_reps=args.reps, max_iter=args.mc_steps, conv_crit=0.0,
                          max_retries=0, seed=20250101, rep_offset=first, device=local_rank,
-                         waves_per_chain=args.waves, debug_flags=args.debug_flags)
+                         waves_per_chain=args.waves, exec_mode=args.mode, debug_flags=args.debug_flags)
     plan = engine.Plan(model.setup(), q, I, sigma, st)
 
     def one_step(seed):

@@ -44,6 +44,14 @@ enum {
     MCSAS_GEN_EXP3 = 3      /* RandomExponential3  :186-189 (10^(3u) - 1)/1000 */
 };
 
+/* exec_mode: how chains are mapped onto the chip (results are identical, only speed differs) */
+enum {
+    MCSAS_EXEC_AUTO = 0,
+    MCSAS_EXEC_WAVE = 1,      /* one wavefront per chain: many repetitions (>= ~1000) */
+    MCSAS_EXEC_WORKGROUP = 2, /* one workgroup per chain, speculative proposal window in LDS */
+    MCSAS_EXEC_PIPELINE = 3   /* producer kernels on every CU + one scan workgroup per chain: few repetitions */
+};
+
 enum {
     MCSAS_OK = 0,
     MCSAS_EINVAL = -1,      /* bad argument / unsupported size */
@@ -105,7 +113,7 @@ typedef struct mcsas_problem {
     int32_t  device;             /* HIP device ordinal, -1 = current device */
     int32_t  waves_per_chain;    /* 0 = auto; 1 = one wavefront per chain; >1 = workgroup per chain */
     int32_t  cache_intensities;  /* -1 auto, 0 re-evaluate `old` every step like mcsas.py:362, 1 keep rows in HBM */
-    int32_t  reserved1;
+    int32_t  exec_mode;          /* MCSAS_EXEC_*: 0 auto, 1 wavefront per chain, 2 workgroup per chain, 3 whole-chip pipeline */
 } mcsas_problem;
 
 /* What mcFit returns per repetition (mcsas.py:428-439) gathered the way analyse() stores it

@@ -52,7 +52,7 @@ class Problem(C.Structure):
         ("replay_stream", _dp), ("replay_len", C.c_int64),
         ("stop", _i32p),
         ("device", C.c_int32), ("waves_per_chain", C.c_int32),
-        ("cache_intensities", C.c_int32), ("reserved1", C.c_int32),
+        ("cache_intensities", C.c_int32), ("exec_mode", C.c_int32),
     ]
 
 

@@ -297,18 +297,29 @@ __device__ __forceinline__ void wg_scanner(const ChainArgs &a, const WgGeom &g, 
                 int k = 0;
                 if (!(cur.chi2 > a.conv_crit) || stopped) k = kmax;      // nothing to do
                 if (a.pad0 & 2) { num_iter += kmax - k; k = kmax; }       // diagnostic: skip the scan
-                for (; k < kmax; ++k) {
-                    const double *dr = dbase + (size_t)k * qpad;
-                    double dl[QPL], h0 = 0., h1 = 0.;
+                // Steps are decided EIGHT at a time: h_g = Σ (w·ft)·d_g for the next eight steps is
+                // valid for all of them as long as none is accepted (the usual case); lane g of every
+                // octet then evaluates step g's decision.  The first accepted step (if any) is applied
+                // and the group restarts behind it — the sequence of decisions is exactly the serial one.
+                const int g = lane & 7;
+                const int gslot = ((g & 1) << 2) | (g & 2) | ((g >> 2) & 1);   // accumulator holding step g (bit-reversed)
+                while (k < kmax) {
+                    const int gcount = (kmax - k) < 8 ? (kmax - k) : 8;
+                    double acc[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
 #pragma unroll
-                    for (int j = 0; j < QPL; ++j) dl[j] = dr[WAVE * j];
+                    for (int j = 0; j < QPL; ++j) {
+                        const double wf = lwft[WAVE * j];
 #pragma unroll
-                    for (int j = 0; j < QPL; j += 2) {
-                        h0 = fma(lwft[WAVE * j], dl[j], h0);
-                        if (j + 1 < QPL) h1 = fma(lwft[WAVE * (j + 1)], dl[j + 1], h1);
+                        for (int gg = 0; gg < 8; ++gg) {
+                            const int kk = (k + gg < K) ? k + gg : K - 1;            // stay inside the window buffer
+                            const int slot = ((gg & 1) << 2) | (gg & 2) | ((gg >> 2) & 1);
+                            acc[slot] = fma(wf, dbase[(size_t)kk * qpad + WAVE * j], acc[slot]);
+                        }
                     }
-                    const double h = wave_sum(h0 + h1);
-                    const double *sc = sbase + k * 4;
+                    const double h = wave_sum8_transposed(acc, lane);               // lane g: h of step k+g
+                    (void)gslot;
+                    const int kg = (k + g < K) ? k + g : K - 1;
+                    const double *sc = sbase + kg * 4;
                     const double SCt = SC + sc[0], SICt = SIC + sc[1], SCCt = SCC + (2. * h + sc[2]);
                     // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
                     double S = a.SII, num = SICt, den = SCCt;
@@ -317,33 +328,48 @@ __device__ __forceinline__ void wg_scanner(const ChainArgs &a, const WgGeom &g, 
                         const bool neg_b = a.pos_bg && (a.SI * denc - numc * SCt < 0.);
                         if (!neg_b) { S = Scen; num = numc; den = denc; }
                     }
-                    if (sh.povf[sb * K + k]) overflow = 1;
-                    if (num * num > (S - X) * den) {                       // chi²_t < chi²  (mcsas.py:379)
-                        double fo[QPL], wv[QPL];
+                    const bool acc_g = (g < gcount) && (num * num > (S - X) * den);   // chi²_t < chi² (mcsas.py:379)
+                    const unsigned amask = (unsigned)(__ballot(acc_g) & 0xFFull);
+                    const unsigned ovm = (unsigned)(__ballot((g < gcount) && sh.povf[sb * K + kg]) & 0xFFull);
+                    if (amask == 0u) {
+                        if (ovm) overflow = 1;
+                        k += gcount; num_iter += gcount;
+                        ri += gcount; if (ri >= N) ri -= N;
+                        continue;
+                    }
+                    const int ga = __builtin_ctz(amask);                            // first accepted step of the group
+                    if (ovm & ((2u << ga) - 1u)) overflow = 1;
+                    const int ka = k + ga;
+                    int ria = ri + ga; if (ria >= N) ria -= N;
+                    {
+                        const double *dr = dbase + (size_t)ka * qpad;
+                        double fo[QPL], wv[QPL], dl[QPL];
 #pragma unroll
-                        for (int j = 0; j < QPL; ++j) { fo[j] = lft[WAVE * j]; wv[j] = sh.lw[lane + WAVE * j]; }
+                        for (int j = 0; j < QPL; ++j) { fo[j] = lft[WAVE * j]; wv[j] = sh.lw[lane + WAVE * j]; dl[j] = dr[WAVE * j]; }
 #pragma unroll
                         for (int j = 0; j < QPL; ++j) {
                             const double f = fo[j] + dl[j];
                             lft[WAVE * j] = f;
                             lwft[WAVE * j] = wv[j] * f;
                         }
-                        SC = SCt; SIC = SICt; SCC = SCCt;
-                        cur = solve_fit(a, SC, SCC, SIC);
-                        X = cur.chi2 * nqd;
-                        const int fresh = sh.stage_slot[sb * K + k];
-                        const int freed = sh.slot_of[ri];
-                        if (lane == 0) {
-                            sh.slot_of[ri] = fresh; sh.stage_slot[sb * K + k] = freed;
-                            for (int p = 0; p < P; ++p)
-                                rset[(size_t)ri * P + p] = sh.pval[((size_t)sb * K + k) * MCSAS_MAX_ACTIVE + p];
-                        }
-                        ++num_moves;
-                        touched = true;
-                        if (!(cur.chi2 > a.conv_crit)) { ri = (ri + 1 == N) ? 0 : ri + 1; ++num_iter; break; }
                     }
-                    ri = (ri + 1 == N) ? 0 : ri + 1;
-                    ++num_iter;
+                    SC = readlane_f64(SCt, ga); SIC = readlane_f64(SICt, ga); SCC = readlane_f64(SCCt, ga);
+                    cur = solve_fit(a, SC, SCC, SIC);
+                    X = cur.chi2 * nqd;
+                    {
+                        const int fresh = sh.stage_slot[sb * K + ka];
+                        const int freed = sh.slot_of[ria];
+                        if (lane == 0) {
+                            sh.slot_of[ria] = fresh; sh.stage_slot[sb * K + ka] = freed;
+                            for (int p = 0; p < P; ++p)
+                                rset[(size_t)ria * P + p] = sh.pval[((size_t)sb * K + ka) * MCSAS_MAX_ACTIVE + p];
+                        }
+                    }
+                    ++num_moves;
+                    touched = true;
+                    k = ka + 1; num_iter += ga + 1;
+                    ri = ria + 1; if (ri >= N) ri -= N;
+                    if (!(cur.chi2 > a.conv_crit)) break;
                 }
                 if (touched) {
                     // re-sum the fit sums from ft so the incremental updates cannot drift

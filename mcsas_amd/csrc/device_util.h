@@ -48,6 +48,54 @@ __device__ __forceinline__ void wave_sum3(double &a, double &b, double &c) {
     a = readlane_f64(a, 63); b = readlane_f64(b, 63); c = readlane_f64(c, 63);
 }
 
+// ---- transposed reduction: eight sums for the price of ~1.5 -------------------------------------
+// In: acc[c], c = 0..7, per-lane partial sums of eight different quantities.  Out: every lane whose
+// low three lane-index bits spell (b0,b1,b2) holds the wave total of quantity c = 4*b0 + 2*b1 + b2.
+// Three halving exchanges (lane xor 1, 2, 4: half of the values travel, half stay) then three plain
+// exchanges (xor 8 by row rotation, xor 16 / 32 with the gfx950 permlane swaps): 70 instructions
+// instead of 8 x 20.
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ double dpp_f64_banks(double old, double v) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xF, BANK_MASK, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xF, BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_xor4(double v) {      // row_shl:4 into banks 0,2; row_shr:4 into banks 1,3
+    double d = dpp_f64_banks<0x104, 0x5>(v, v);
+    return dpp_f64_banks<0x114, 0xA>(d, v);
+}
+__device__ __forceinline__ double sum_xor16(double v) {      // v[i] + v[i^16]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ double sum_xor32(double v) {      // v[i] + v[i^32]
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double(h[0], l[0]) + __hiloint2double(h[1], l[1]);
+}
+__device__ __forceinline__ double wave_sum8_transposed(const double (&acc)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    double a4[4], a2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double keep = b0 ? acc[i + 4] : acc[i], send = b0 ? acc[i] : acc[i + 4];
+        a4[i] = keep + dpp_f64<0xB1>(send);                  // quad_perm [1,0,3,2]
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = b1 ? a4[i + 2] : a4[i], send = b1 ? a4[i] : a4[i + 2];
+        a2[i] = keep + dpp_f64<0x4E>(send);                  // quad_perm [2,3,0,1]
+    }
+    const double keep = b2 ? a2[1] : a2[0], send = b2 ? a2[0] : a2[1];
+    double a1 = keep + lane_xor4(send);
+    a1 += dpp_f64<0x128>(a1);                                // row_ror:8 == lane xor 8
+    a1 = sum_xor16(a1);
+    return sum_xor32(a1);
+}
+
 __device__ __forceinline__ double wave_min(double v) {
     v = fmin(v, __shfl_xor(v, 1)); v = fmin(v, __shfl_xor(v, 2));
     v = fmin(v, __shfl_xor(v, 4)); v = fmin(v, __shfl_xor(v, 8));

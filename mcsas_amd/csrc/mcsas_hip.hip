@@ -15,6 +15,7 @@
 #include "../../include/mcsas_hip.h"
 #include "chain_common.h"
 #include "chain_wg.h"   // WgGeom / wg_geometry only; the kernels are instantiated in kern_*.hip
+#include "chain_pipe.h" // PipeArgs / pipe_geometry only
 
 using namespace mcsas;
 
@@ -170,12 +171,36 @@ struct mcsas_plan {
     double last_ms = 0.;
     int64_t last_steps = 0;
     WgGeom wg{};
+    // whole-chip pipeline (exec_mode 3)
+    int mode = MCSAS_EXEC_WAVE;
+    PipeArgs pipe{};
+    PipeChain *d_chains = nullptr;
+    double *d_ft = nullptr, *d_wft = nullptr, *d_dwin = nullptr, *d_scal = nullptr, *d_pval = nullptr;
+    int32_t *d_slot_of = nullptr, *d_stage = nullptr, *d_povf = nullptr;
+    int32_t *h_done = nullptr;          // pinned + mapped: scan kernels count finished chains into it
+    hipStream_t sP = nullptr, sS = nullptr;
+    static constexpr int RING = 64;
+    hipEvent_t evP[RING] = {}, evS[RING] = {};
+    int ticks_launched = 0;
 };
 
 // kernel lookups, one translation unit per model (kern_wave.hip / kern_wg.hip)
 void *mcsas_wave_kernel_m0(int, bool); void *mcsas_wave_kernel_m1(int, bool);
 void *mcsas_wave_kernel_m2(int, bool); void *mcsas_wave_kernel_m3(int, bool);
 void *mcsas_wg_kernel_m0(int); void *mcsas_wg_kernel_m1(int); void *mcsas_wg_kernel_m2(int); void *mcsas_wg_kernel_m3(int);
+void *mcsas_pipe_prod_kernel_m0(int); void *mcsas_pipe_prod_kernel_m1(int);
+void *mcsas_pipe_prod_kernel_m2(int); void *mcsas_pipe_prod_kernel_m3(int);
+void *mcsas_pipe_scan_kernel(int); void *mcsas_pipe_reset_kernel();
+
+static void *pipe_prod_kernel_for(int model, int qpl) {
+    switch (model) {
+        case MCSAS_MODEL_SPHERE: return mcsas_pipe_prod_kernel_m0(qpl);
+        case MCSAS_MODEL_CYL_ISO: return mcsas_pipe_prod_kernel_m1(qpl);
+        case MCSAS_MODEL_ELL_CS: return mcsas_pipe_prod_kernel_m2(qpl);
+        case MCSAS_MODEL_KHOLODENKO: return mcsas_pipe_prod_kernel_m3(qpl);
+        default: return nullptr;
+    }
+}
 
 static void *wave_kernel_for(int model, int qpl, bool cache) {
     switch (model) {
@@ -201,6 +226,15 @@ extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     hipFree(pl->d_q); hipFree(pl->d_w); hipFree(pl->d_wI); hipFree(pl->d_I);
     hipFree(pl->d_rset); hipFree(pl->d_cache); hipFree(pl->d_fit); hipFree(pl->d_replay); hipFree(pl->d_out);
     if (pl->h_stop) hipHostFree(pl->h_stop);
+    if (pl->h_done) hipHostFree(pl->h_done);
+    hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_scal);
+    hipFree(pl->d_pval); hipFree(pl->d_slot_of); hipFree(pl->d_stage); hipFree(pl->d_povf);
+    for (int i = 0; i < mcsas_plan::RING; ++i) {
+        if (pl->evP[i]) hipEventDestroy(pl->evP[i]);
+        if (pl->evS[i]) hipEventDestroy(pl->evS[i]);
+    }
+    if (pl->sP) hipStreamDestroy(pl->sP);
+    if (pl->sS) hipStreamDestroy(pl->sS);
     if (pl->ev0) hipEventDestroy(pl->ev0);
     if (pl->ev1) hipEventDestroy(pl->ev1);
     delete pl;
@@ -242,10 +276,27 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     // q slots per lane: power of two so the kernels are fully unrolled
     int qpl = 1;
     while (qpl * WAVE < p->nq) qpl *= 2;
-    const int waves = p->waves_per_chain > 0 ? p->waves_per_chain : 1;
-    if (waves == 1 && qpl > 16) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 1024 needs waves_per_chain > 1", p->nq); }
+    if (qpl > 16) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 1024 is not supported", p->nq); }
     const int qpad = qpl * WAVE;
-    pl->qpl = qpl; pl->waves = waves;
+    const int tabd = table_doubles_host(p->model_id, margs.int_div);
+    // execution mode (results do not depend on it)
+    int mode = p->exec_mode;
+    int waves = p->waves_per_chain;
+    if (mode == MCSAS_EXEC_AUTO) {
+        if (waves == 1) mode = MCSAS_EXEC_WAVE;
+        else if (waves > 1) mode = MCSAS_EXEC_WORKGROUP;
+        else {
+            PipeGeom pg; WgGeom wgm;
+            if (p->n_reps >= 1024) mode = MCSAS_EXEC_WAVE;
+            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, tabd, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
+            else if (wg_geometry(p->nq, p->n_contrib, tabd, WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
+            else mode = MCSAS_EXEC_WAVE;
+        }
+    }
+    if (mode == MCSAS_EXEC_WORKGROUP && waves < 2) waves = WG_MAX_WAVES;
+    if (mode != MCSAS_EXEC_WORKGROUP) waves = 1;
+    if (mode < MCSAS_EXEC_WAVE || mode > MCSAS_EXEC_PIPELINE) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "exec_mode %d", mode); }
+    pl->qpl = qpl; pl->waves = waves; pl->mode = mode;
 
     // padded data vectors; sigma == 0 -> 1 (backgroundscalingfit.py:117)
     std::vector<double> hq(qpad), hw(qpad, 0.), hwI(qpad, 0.), hI(qpad, 0.);
@@ -270,20 +321,23 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     PCHK(hipMalloc(&pl->d_out, sizeof(ChainOut) * R));
     PCHK(hipMemset(pl->d_out, 0, sizeof(ChainOut) * R));
 
-    // per-contribution intensity rows: the workgroup kernel adds one spare row per window slot
+    // per-contribution intensity rows: the speculative kernels add two windows of spare row slots
     int cache_rows = (int)N;
-    if (waves > 1) {
-        int rcg = wg_geometry(p->nq, (int)N, table_doubles_host(p->model_id, margs.int_div), waves, &pl->wg);
-        if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: problem does not fit LDS (nq=%d)", p->nq); }
+    if (mode == MCSAS_EXEC_WORKGROUP) {
+        int rcg = wg_geometry(p->nq, (int)N, tabd, waves, &pl->wg);
+        if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: needs 2*window <= n_contrib and the window in LDS (nq=%d, n_contrib=%d, waves=%d)", p->nq, (int)N, waves); }
         cache_rows = (int)N + 2 * pl->wg.window;
+    } else if (mode == MCSAS_EXEC_PIPELINE) {
+        if (pipe_geometry(p->nq, (int)N, tabd, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
+        cache_rows = (int)N + 2 * pl->pipe.g.kb;
     }
     size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
     int use_cache = p->cache_intensities;
-    if (use_cache < 0 || waves > 1) {
+    if (use_cache < 0 || mode != MCSAS_EXEC_WAVE) {
         size_t fr = 0, tot = 0;
         PCHK(hipMemGetInfo(&fr, &tot));
         use_cache = cache_bytes < fr / 2;
-        if (waves > 1 && !use_cache) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_ENOMEM, "intensity cache (%zu MB) does not fit", cache_bytes >> 20); }
+        if (mode != MCSAS_EXEC_WAVE && !use_cache) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_ENOMEM, "intensity cache (%zu MB) does not fit", cache_bytes >> 20); }
     }
     pl->use_cache = use_cache;
     if (use_cache) PCHK(hipMalloc(&pl->d_cache, cache_bytes));
@@ -318,11 +372,37 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     a.stop_flag = d_stop;
     a.rset = pl->d_rset; a.cache = pl->d_cache; a.cache_rows = cache_rows; a.fit = pl->d_fit; a.out = pl->d_out;
 
-    if (waves == 1) {
-        pl->lds_bytes = sizeof(double) * (4 * (size_t)qpad + table_doubles_host(p->model_id, margs.int_div));
+    if (mode == MCSAS_EXEC_WAVE) {
+        pl->lds_bytes = sizeof(double) * (4 * (size_t)qpad + tabd);
         if (!wave_kernel_for(p->model_id, qpl, use_cache)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no kernel for model %d qpl %d", p->model_id, qpl); }
-    } else {
+    } else if (mode == MCSAS_EXEC_WORKGROUP) {
         pl->lds_bytes = pl->wg.lds_bytes;
+    } else {
+        PipeArgs &pa = pl->pipe;
+        const size_t Kb = pa.g.kb;
+        PCHK(hipMalloc(&pl->d_chains, sizeof(PipeChain) * R));
+        PCHK(hipMalloc(&pl->d_ft, sizeof(double) * R * qpad)); PCHK(hipMalloc(&pl->d_wft, sizeof(double) * R * qpad));
+        PCHK(hipMalloc(&pl->d_slot_of, sizeof(int32_t) * R * N)); PCHK(hipMalloc(&pl->d_stage, sizeof(int32_t) * R * 2 * Kb));
+        PCHK(hipMalloc(&pl->d_dwin, sizeof(double) * R * 2 * Kb * qpad));
+        PCHK(hipMalloc(&pl->d_scal, sizeof(double) * R * 2 * Kb * 4));
+        PCHK(hipMalloc(&pl->d_pval, sizeof(double) * R * 2 * Kb * MCSAS_MAX_ACTIVE));
+        PCHK(hipMalloc(&pl->d_povf, sizeof(int32_t) * R * 2 * Kb));
+        PCHK(hipMemset(pl->d_povf, 0, sizeof(int32_t) * R * 2 * Kb));
+        PCHK(hipHostMalloc((void **)&pl->h_done, sizeof(int32_t), hipHostMallocMapped));
+        *pl->h_done = 0;
+        int32_t *d_done = nullptr;
+        PCHK(hipHostGetDevicePointer((void **)&d_done, pl->h_done, 0));
+        PCHK(hipStreamCreateWithFlags(&pl->sP, hipStreamNonBlocking));
+        PCHK(hipStreamCreateWithFlags(&pl->sS, hipStreamNonBlocking));
+        for (int i = 0; i < mcsas_plan::RING; ++i) {
+            PCHK(hipEventCreateWithFlags(&pl->evP[i], hipEventDisableTiming));
+            PCHK(hipEventCreateWithFlags(&pl->evS[i], hipEventDisableTiming));
+        }
+        pa.c = a;
+        pa.chains = pl->d_chains; pa.ft = pl->d_ft; pa.wft = pl->d_wft; pa.slot_of = pl->d_slot_of;
+        pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.scal = pl->d_scal; pa.pval = pl->d_pval;
+        pa.povf = pl->d_povf; pa.n_done = d_done; pa.tick = 0;
+        pl->lds_bytes = std::max(pa.g.prod_lds, pa.g.scan_lds);
     }
     if (pl->lds_bytes > 160 * 1024) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "LDS need %zu B > 160 KiB", pl->lds_bytes); }
     *out = pl;
@@ -336,25 +416,82 @@ extern "C" int mcsas_hip_plan_reseed(mcsas_plan *pl, uint64_t seed, int32_t rep_
     return MCSAS_OK;
 }
 
+static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
+    PipeArgs &pa = pl->pipe;
+    pa.c = pl->args;                                     // picks up reseed()
+    const int R = pl->prob.n_reps, Kb = pa.g.kb;
+    void *prod = pipe_prod_kernel_for(pl->prob.model_id, pl->qpl), *scan = mcsas_pipe_scan_kernel(pl->qpl);
+    void *reset = mcsas_pipe_reset_kernel();
+    if (!prod || !scan) return fail(MCSAS_EINVAL, "no pipeline kernel for model %d qpl %d", pl->prob.model_id, pl->qpl);
+    if (pa.g.prod_lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(prod, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pa.g.prod_lds));
+    if (pa.g.scan_lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pa.g.scan_lds));
+    *pl->h_done = 0;
+    HIPCHK(hipEventRecord(pl->ev0, st));
+    HIPCHK(hipStreamWaitEvent(pl->sS, pl->ev0, 0));
+    {
+        void *ka[] = {(void *)&pa};
+        HIPCHK(hipLaunchKernel(reset, dim3((R + 63) / 64), dim3(64), ka, 0, pl->sS));
+    }
+    HIPCHK(hipEventRecord(pl->evS[mcsas_plan::RING - 1], pl->sS));
+    HIPCHK(hipStreamWaitEvent(pl->sP, pl->evS[mcsas_plan::RING - 1], 0));
+    // worst case: every attempt runs to max_iter
+    const long long win_per_attempt = (long long)((pl->prob.max_iter + Kb - 1) / Kb) + 3;
+    const long long max_ticks = std::min<long long>((long long)(pl->prob.max_retries + 1) * win_per_attempt + 4, 2000000000LL);
+    const dim3 pgrid(R, pa.g.prod_blocks_y), sgrid(R);
+    int t = 0;
+    for (; t < max_ticks; ++t) {
+        const int r = t % mcsas_plan::RING;
+        if (t >= mcsas_plan::RING / 2 && (t % 8) == 0) {
+            // throttle: stay at most RING/2 ticks ahead of the GPU, forward the stop word, leave when all chains are done
+            HIPCHK(hipEventSynchronize(pl->evS[(t - mcsas_plan::RING / 2) % mcsas_plan::RING]));
+            if (pl->prob.stop && *pl->prob.stop) *pl->h_stop = 1;
+            if (*(volatile int32_t *)pl->h_done >= R) break;
+        }
+        pa.tick = t;
+        void *ka[] = {(void *)&pa};
+        if (t >= 2) HIPCHK(hipStreamWaitEvent(pl->sP, pl->evS[(t - 2) % mcsas_plan::RING], 0));
+        HIPCHK(hipLaunchKernel(prod, pgrid, dim3(256), ka, pa.g.prod_lds, pl->sP));
+        HIPCHK(hipEventRecord(pl->evP[r], pl->sP));
+        HIPCHK(hipStreamWaitEvent(pl->sS, pl->evP[r], 0));
+        HIPCHK(hipLaunchKernel(scan, sgrid, dim3(64 * pa.g.scan_waves), ka, pa.g.scan_lds, pl->sS));
+        HIPCHK(hipEventRecord(pl->evS[r], pl->sS));
+    }
+    pl->ticks_launched = t;
+    // join both internal streams back into the caller's stream
+    HIPCHK(hipEventRecord(pl->evP[mcsas_plan::RING - 1], pl->sP));
+    HIPCHK(hipEventRecord(pl->evS[mcsas_plan::RING - 2], pl->sS));
+    HIPCHK(hipStreamWaitEvent(st, pl->evP[mcsas_plan::RING - 1], 0));
+    HIPCHK(hipStreamWaitEvent(st, pl->evS[mcsas_plan::RING - 2], 0));
+    HIPCHK(hipEventRecord(pl->ev1, st));
+    return MCSAS_OK;
+}
+
 extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
     if (!pl) return fail(MCSAS_EINVAL, "null plan");
     HIPCHK(hipSetDevice(pl->dev));
     hipStream_t st = (hipStream_t)hip_stream;
     *pl->h_stop = (pl->prob.stop && *pl->prob.stop) ? 1 : 0;
+    if (pl->mode == MCSAS_EXEC_PIPELINE) {
+        int rc = pipeline_launch(pl, st);
+        if (rc) return rc;
+        pl->stream = st; pl->launched = true;
+        return MCSAS_OK;
+    }
     void *kargs[] = {(void *)&pl->args};
     void *fn;
     dim3 grid(pl->prob.n_reps), block;
-    if (pl->waves == 1) {
+    if (pl->mode == MCSAS_EXEC_WAVE) {
         fn = wave_kernel_for(pl->prob.model_id, pl->qpl, pl->use_cache);
         block = dim3(WAVE);
     } else {
         fn = wg_kernel_for(pl->prob.model_id, pl->qpl);
         block = dim3(WAVE * pl->waves);
     }
+    if (!fn) return fail(MCSAS_EINVAL, "no kernel for model %d qpl %d", pl->prob.model_id, pl->qpl);
     if (pl->lds_bytes > 64 * 1024)
         HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl->lds_bytes));
     HIPCHK(hipEventRecord(pl->ev0, st));
-    if (pl->waves == 1) {
+    if (pl->mode == MCSAS_EXEC_WAVE) {
         HIPCHK(hipLaunchKernel(fn, grid, block, kargs, pl->lds_bytes, st));
     } else {
         void *kargs2[] = {(void *)&pl->args, (void *)&pl->wg};

@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import MAX_ACTIVE, MAX_PARAMS, Problem, Result, as_dp, check, f64
 
 MODEL_SPHERE, MODEL_CYL_ISO, MODEL_ELL_CS, MODEL_KHOLODENKO = 0, 1, 2, 3
+EXEC_AUTO, EXEC_WAVE, EXEC_WORKGROUP, EXEC_PIPELINE = 0, 1, 2, 3
 GEN_UNIFORM, GEN_EXP1, GEN_EXP2, GEN_EXP3 = 0, 1, 2, 3
 INT64_MAX = (1 << 63) - 1
 
@@ -57,6 +58,7 @@ class Settings:
     device: int = -1
     waves_per_chain: int = 0
     cache_intensities: int = -1
+    exec_mode: int = 0                 # MCSAS_EXEC_*: 0 auto, 1 wave, 2 workgroup, 3 pipeline
     debug_flags: int = 0               # diagnostic only (role ablation in the workgroup kernel)
 
 
@@ -110,6 +112,7 @@ class HipProblem:
         p.device = int(st.device)
         p.waves_per_chain = int(st.waves_per_chain)
         p.cache_intensities = int(st.cache_intensities)
+        p.exec_mode = int(st.exec_mode)
         self.c = p
 
 

@@ -57,12 +57,13 @@ class McSAS(object):
     def factory(cls):                                        # mcsas.py:143-147
         return cls
 
-    def __init__(self, seed=None, device=-1, wavesPerChain=0):
+    def __init__(self, seed=None, device=-1, wavesPerChain=0, execMode=0):
         for name, default, rng in _DEFAULTS:
             setattr(self, name, _Setting(name, default, rng))
         self.seed = seed
         self.device = device
         self.wavesPerChain = wavesPerChain
+        self.execMode = execMode
         self._stop = C.c_int32(0)
         self.details = None
 
@@ -100,7 +101,7 @@ class McSAS(object):
             find_background=self.findBackground.value(), positive_background=self.positiveBackground.value(),
             start_from_minimum=self.startFromMinimum(), max_retries=int(self.maxRetries()),
             show_incomplete=self.showIncomplete(), seed=seed, device=self.device,
-            waves_per_chain=self.wavesPerChain)
+            waves_per_chain=self.wavesPerChain, exec_mode=self.execMode)
 
     def analyse(self, replay=None):                          # mcsas.py:191-285
         if self.result is None:

@@ -55,14 +55,17 @@ TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q5
 
 
 @pytest.mark.parametrize("name", TRAJ)
-@pytest.mark.parametrize("cache,waves", [(1, 1), (0, 1), (1, 8), (1, 3)])
+@pytest.mark.parametrize("cache,waves", [(1, 1), (0, 1), (1, 8), (1, 3), (1, -3)])
 def test_replay_trajectories_vs_reference(name, cache, waves):
     """The uniform stream the reference consumed, replayed on the GPU, gives the reference's
     accept/reject trajectory: same iteration count, same number of moves, same final parameter
     set, chi-squared within 1e-7."""
     g, m, spec, st, ost = traj_setup(name)
     st.cache_intensities = cache
-    st.waves_per_chain = waves
+    if waves == -3:                      # whole-chip pipeline
+        st.exec_mode, st.waves_per_chain = engine.EXEC_PIPELINE, 0
+    else:
+        st.waves_per_chain = waves
     if waves > 1 and 2 * (waves - 1) > st.n_contrib:
         pytest.skip("window does not fit 2K <= N")
     res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st,
@@ -77,7 +80,7 @@ def test_replay_trajectories_vs_reference(name, cache, waves):
     assert res.draws[0] == (0 if st.start_from_minimum else ost.n_contrib * spec.n_active) + res.num_iter[0] * spec.n_active
 
 
-@pytest.mark.parametrize("waves", [1, 8])
+@pytest.mark.parametrize("waves", [1, 8, -3])
 def test_analyse_reps_retries_and_result_dict(waves):
     """McSAS.analyse with 2 reps x 3 attempts (maxRetries=2, showIncomplete) against the reference
     run; each rep replays its own slice of the reference's single global stream."""
@@ -90,7 +93,8 @@ def test_analyse_reps_retries_and_result_dict(waves):
     L = max(i["end"] - i["start"] for i in info) + 8
     replay = np.stack([np.resize(g["B_stream"][i["start"]:], L) for i in info])
     algo = mcsas_amd.McSAS.factory()()
-    algo.wavesPerChain = waves
+    algo.wavesPerChain = max(waves, 0)
+    algo.execMode = engine.EXEC_PIPELINE if waves == -3 else 0
     algo.numContribs.setValue(50); algo.numReps.setValue(2); algo.maxIterations.setValue(60)
     algo.convergenceCriterion.setValue(1e-9); algo.maxRetries.setValue(2); algo.showIncomplete.setValue(True)
     algo.model = m
@@ -151,7 +155,7 @@ def test_calc_converges_and_histogram_matches_reference():
         np.testing.assert_allclose(np.array(h.moments.fields)[0::2], g[p + "moments"][0::2], rtol=1e-6)
 
 
-@pytest.mark.parametrize("waves", [1, 8, 5])
+@pytest.mark.parametrize("waves", [1, 8, 5, -3])
 def test_free_running_philox_matches_oracle(waves):
     """Free-running chains (device Philox) follow the oracle run with the same counter-based stream:
     identical decisions, parameter sets and iteration counts for every rep."""
@@ -159,7 +163,7 @@ def test_free_running_philox_matches_oracle(waves):
     q, I, sig = g["data_q"], g["data_I"], g["data_sigma"]
     m, spec = make_models("sphere", g["spec_lo"], g["spec_hi"])
     st = engine.Settings(n_contrib=80, n_reps=4, max_iter=500, conv_crit=1e-9, max_retries=0, seed=20250101, rep_offset=3,
-                         waves_per_chain=waves)
+                         waves_per_chain=max(waves, 0), exec_mode=engine.EXEC_PIPELINE if waves == -3 else 0)
     res = engine.analyse(m.setup(), q, I, sig, st)
     ost = O.Settings(n_contrib=80, n_reps=1, max_iter=500, conv_crit=1e-9)
     for r in range(4):
@@ -171,7 +175,7 @@ def test_free_running_philox_matches_oracle(waves):
     assert len(set(res.num_moves.tolist())) > 1 or len(set(np.round(res.chisq, 6).tolist())) > 1
 
 
-@pytest.mark.parametrize("waves", [1, 8])
+@pytest.mark.parametrize("waves", [1, 8, -3])
 def test_full_size_properties_config2(waves):
     """BASELINE config 2 shape (512 q x 400 contribs x 50 reps), fixed budget: size-independent
     properties — chi² decreases monotonically with the step budget on the same seed, reported chi²
@@ -182,7 +186,7 @@ def test_full_size_properties_config2(waves):
     chis = []
     for steps in (200, 2000):
         st = engine.Settings(n_contrib=400, n_reps=50, max_iter=steps, conv_crit=0.0, max_retries=0, seed=7,
-                             waves_per_chain=waves)
+                             waves_per_chain=max(waves, 0), exec_mode=engine.EXEC_PIPELINE if waves == -3 else 0)
         res = engine.analyse(m.setup(), q, I, sig, st)
         assert (res.num_iter == steps).all()
         direct = (((I[:, None] - res.fit) / sig[:, None])**2).sum(axis=0) / len(q)

@@ -53,6 +53,21 @@ __global__ void k_sincos(double *out, int iters) {
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (double)(t1 - t0);
 }
 
+__global__ void k_reduce8(double *out, int iters) {
+    double acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = threadIdx.x * (i + 1);
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    double v = 0;
+    for (int it = 0; it < iters; ++it) {
+        v = mcsas::wave_sum8_transposed(acc, threadIdx.x);
+        for (int i = 0; i < 8; ++i) acc[i] = acc[i] * 1e-3 + v * 1e-6 + threadIdx.x * (i + 1);
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    // check: quantity c total = (c+1) * sum(lane) = (c+1)*2016 at iters == 1
+    out[threadIdx.x + 64] = v;
+    if (threadIdx.x == 0) out[0] = (double)(t1 - t0);
+}
+
 int main() {
     double *d; hipMalloc(&d, 1 << 20);
     double h[2];
@@ -73,6 +88,17 @@ int main() {
     hipLaunchKernelGGL(k_reduce, dim3(1), dim3(64), 0, 0, d, 1000); hipDeviceSynchronize();
     hipMemcpy(h, d, 8, hipMemcpyDeviceToHost);
     printf("wave_sum (6 DPP stages + readlane, dependent): %.1f cycles each\n", h[0] / 1000);
+    hipLaunchKernelGGL(k_reduce8, dim3(1), dim3(64), 0, 0, d, 1); hipDeviceSynchronize();
+    {
+        std::vector<double> hv(128);
+        hipMemcpy(hv.data(), d, 128 * 8, hipMemcpyDeviceToHost);
+        int bad = 0;
+        for (int l = 0; l < 64; ++l) { int c = 4 * (l & 1) + 2 * ((l >> 1) & 1) + ((l >> 2) & 1); if (hv[64 + l] != (c + 1) * 2016.0) ++bad; }
+        printf("wave_sum8_transposed: %d wrong lanes (expect 0)\n", bad);
+    }
+    hipLaunchKernelGGL(k_reduce8, dim3(1), dim3(64), 0, 0, d, 1000); hipDeviceSynchronize();
+    hipMemcpy(h, d, 8, hipMemcpyDeviceToHost);
+    printf("wave_sum8_transposed (8 sums, dependent): %.1f cycles each\n", h[0] / 1000);
     for (int waves : {1, 4, 8}) {
         hipLaunchKernelGGL(k_sincos, dim3(1), dim3(64 * waves), 0, 0, d, 1000); hipDeviceSynchronize();
         hipMemcpy(h, d, 8, hipMemcpyDeviceToHost);
