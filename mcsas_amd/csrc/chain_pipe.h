@@ -1,16 +1,17 @@
 // chain_pipe.h — the speculative proposal window of chain_wg.h spread over the WHOLE chip for runs
 // with fewer chains than CUs (BASELINE config 2: 50 chains on 256 CUs).
 //
-// Two kernels per "tick", on two HIP streams:
-//   pipe_prod_kernel  (grid = chains x row blocks, every CU): the form-factor rows of one window of
-//       Kb steps per chain -> `new` row into a spare HBM row slot, d = new - old and the three
-//       ft-independent sums into the window buffer in HBM;
-//   pipe_scan_kernel  (grid = chains, one workgroup each): loader waves stage the window's d rows
-//       HBM -> LDS in sub-windows, the scanner wave makes the accept/reject decisions eight steps at
-//       a time (same arithmetic as chain_wg.h).
-// PROD(t+1) runs concurrently with SCAN(t): a window's rows depend only on the random stream and
-// on row slots settled two windows earlier (2*Kb <= N), never on the decisions of the window
-// before.  Dependencies between launches are HIP events; there are no in-kernel spin waits.
+// One launch per "tick" t (pipe_tick_kernel), two kinds of workgroup in its grid:
+//   scan blocks (one per chain, block ids 0..R-1) do SCAN(t): seven loader waves stage window t's d
+//       rows HBM -> LDS in sub-windows (loads issued one sub-window ahead), the scanner wave makes
+//       the accept/reject decisions eight steps at a time (same arithmetic as chain_wg.h);
+//   producer blocks (the rest of the grid, every CU) do PROD(t+1): the form-factor rows of the NEXT
+//       window of Kb steps per chain -> `new` row into a spare HBM row slot, d = new - old and the
+//       three ft-independent sums into the window buffer in HBM.
+// The two run concurrently inside one launch because a window's rows depend only on the random
+// stream and on row slots settled two windows earlier (2*Kb <= N), never on the decisions of the
+// window before.  Launch t+1 follows launch t on the same stream: the kernel boundary is the only
+// synchronisation; there are no in-kernel spin waits and no cross-workgroup flags.
 //
 // Chain schedule: an attempt (one mcFit call) is initialised at tick t_init (PROD evaluates the N
 // rows of the initial set, SCAN sums them and fits), then tick t > t_init handles window
@@ -61,46 +62,48 @@ struct PipeArgs {
     int32_t pad;
 };
 
+constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
+constexpr int PIPE_RING = 4;         // rows each scan wave keeps in flight / in its private LDS ring
+
 static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, PipeGeom *g) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
     const int qpad = qpl * 64;
-    int kb = 128;
-    while (kb > 8 && 2 * kb > n_contrib) kb /= 2;
-    if (2 * kb > n_contrib) return 1;
-    g->kb = kb; g->qpl = qpl;
-    g->rows_per_wave = kb >= 32 ? 8 : (kb >= 16 ? 4 : 2);
-    g->prod_blocks_y = kb / (4 * g->rows_per_wave);
-    if (g->prod_blocks_y < 1) { g->prod_blocks_y = 1; g->rows_per_wave = kb / 4; }
+    // window: as many steps as 2*Kb <= N allows (a multiple of the 8 producer waves x rows per wave)
+    int rpw = 8;
+    while (rpw > 1 && 2 * 8 * rpw > n_contrib) rpw /= 2;
+    if (2 * 8 * rpw > n_contrib) return 1;
+    int by = n_contrib / (2 * 8 * rpw);
+    if (by * 8 * rpw > 256) by = 256 / (8 * rpw);
+    g->kb = by * 8 * rpw; g->qpl = qpl;
+    g->rows_per_wave = rpw;
+    g->prod_blocks_y = by;
     g->prod_lds = sizeof(double) * (4 * (size_t)qpad + tab_doubles);
-    // scan: w, wI, ft, wft + 2 sub-window buffers of ks rows + scalars
-    int ks = 16;
-    while (ks > 8 && sizeof(double) * ((4 + 2 * (size_t)ks) * qpad + 2 * ks * 4) + 1024 > 150 * 1024) ks /= 2;
-    if (ks > kb) ks = kb;
-    g->ks = ks; g->scan_waves = 4;
-    g->scan_lds = sizeof(double) * ((4 + 2 * (size_t)ks) * qpad + 2 * ks * 4) + 2 * ks * 4 + 64;
+    // scan block LDS: w, wI, ft, wft + one private ring of PIPE_RING rows per wave + the window's scalars/tables
+    g->ks = 8; g->scan_waves = PIPE_BLOCK / 64;
+    g->scan_lds = sizeof(double) * ((4 + (size_t)g->scan_waves * PIPE_RING) * qpad + (size_t)g->kb * 4 + 16)
+                + sizeof(int32_t) * (4 * g->kb + 32) + 64;
     if (g->scan_lds > 160 * 1024) return 1;
     return 0;
 }
 
 // ------------------------------------------------------------------------------------ producer
 template <int M, int QPL>
-__global__ __launch_bounds__(256) void pipe_prod_kernel(const PipeArgs pa) {
-    extern __shared__ double lds[];
+__device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds, int rep, int by, int gy, int t) {
     const ChainArgs &a = pa.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rep = blockIdx.x, by = blockIdx.y, t = pa.tick;
+    constexpr int WPB = PIPE_BLOCK / 64;
     const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb;
     const PipeSnap sn = pa.chains[rep].snap[t & 1];
     if (!sn.alive || t < sn.t_init) return;
 
     double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
-    for (int i = tid; i < qpad; i += 256) {
+    for (int i = tid; i < qpad; i += PIPE_BLOCK) {
         const double qq = a.q[i];
         lq[i] = qq; lw[i] = a.w[i]; lwI[i] = a.wI[i]; lq3[i] = 1.0 / (qq * qq * qq);
     }
-    Contrib<M>::fill_table(a.model, tab, tid, 256);
+    Contrib<M>::fill_table(a.model, tab, tid, PIPE_BLOCK);
     __syncthreads();
     const QTables qt{lq, lq3, tab};
     double *rset = a.rset + (size_t)rep * N * P;
@@ -109,12 +112,12 @@ __global__ __launch_bounds__(256) void pipe_prod_kernel(const PipeArgs pa) {
                          (uint32_t)(a.rep_offset + rep)};
     int32_t *slot_of = pa.slot_of + (size_t)rep * N;
     int32_t *stage = pa.stage_slot + (size_t)rep * 2 * Kb;
-    const int gw = by * 4 + wave, nw = gridDim.y * 4;        // this wave's index among the chain's producer waves
+    const int gw = by * WPB + wave, nw = gy * WPB;          // this wave's index among the chain's producer waves
 
     if (t == sn.t_init) {
         // ---- initial parameter set of the attempt (mcsas.py:310-319): rows n = gw*64 + lane + 64*nw*i
-        for (int i = tid + by * 256; i < N; i += 256 * gridDim.y) slot_of[i] = i;
-        for (int i = tid + by * 256; i < 2 * Kb; i += 256 * gridDim.y) stage[i] = N + i;
+        for (int i = tid + by * PIPE_BLOCK; i < N; i += PIPE_BLOCK * gy) slot_of[i] = i;
+        for (int i = tid + by * PIPE_BLOCK; i < 2 * Kb; i += PIPE_BLOCK * gy) stage[i] = N + i;
         int ovf = 0;
         // contribution n = lane*nw + gw + 64*nw*i: every producer wave of the chain owns ~N/nw rows
         for (int nb = 0; nb < N; nb += nw * WAVE) {
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(256) void pipe_prod_kernel(const PipeArgs pa) {
         return;
     }
 
+    if (a.pad0 & 16) return;                                  // diagnostic: no window rows
     // ---- window w of the attempt: this wave's rows k = gw*rpw .. +rpw-1, one proposal per lane
     const int64_t w = (int64_t)t - sn.t_init - 1;
     const int rpw = pa.g.rows_per_wave, buf = t & 1;
@@ -216,22 +220,23 @@ __global__ __launch_bounds__(256) void pipe_prod_kernel(const PipeArgs pa) {
 // ------------------------------------------------------------------------------------ scanner
 // LDS: lw, lwI, lft, lwft [qpad each]; dsub[2][ks][qpad]; ssub[2][ks][4]; osub[2][ks] (int)
 template <int QPL>
-__global__ __launch_bounds__(256) void pipe_scan_kernel(const PipeArgs pa) {
-    extern __shared__ double lds[];
+__device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds, int rep, int t) {
     const ChainArgs &a = pa.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rep = blockIdx.x, t = pa.tick;
-    const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb, Ks = pa.g.ks;
-    const int NW = pa.g.scan_waves, NL = NW - 1, T = NW * WAVE;
+    const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb;
+    const int NW = pa.g.scan_waves, T = NW * WAVE;
     PipeChain &ch = pa.chains[rep];
     if (ch.done) return;                                      // uniform for the block
     const PipeSnap sn = ch.snap[(t + 1) & 1];                 // the record in force for tick t (written at t-1; host for t = 0)
 
     double *lw = lds, *lwI = lds + qpad, *lft = lds + 2 * qpad, *lwft = lds + 3 * qpad;
-    double *dsub = lds + 4 * qpad;                            // [2][Ks][qpad]
-    double *ssub = dsub + 2 * (size_t)Ks * qpad;              // [2][Ks][4]
-    int32_t *osub = reinterpret_cast<int32_t *>(ssub + 2 * Ks * 4);   // [2][Ks]
-    int32_t *ctl = osub + 2 * Ks;                             // [4]
+    double *ring = lds + (4 + (size_t)wave * PIPE_RING) * qpad;            // this wave's PIPE_RING rows
+    double *ssub = lds + (4 + (size_t)NW * PIPE_RING) * qpad;              // [Kb][4] scalars of the whole window
+    double *hbuf = ssub + (size_t)Kb * 4;                                  // [8] h of the current group, by step offset
+    int32_t *osub = reinterpret_cast<int32_t *>(hbuf + 16);                // [Kb] replay-overflow flags
+    int32_t *lstage = osub + Kb, *lslot = lstage + Kb;          // [Kb] spare row slot of step k / row slot of its contribution
+    int32_t *lacc = lslot + Kb;                                // [Kb + 1] accepted steps of this window, count in lacc[Kb]
+    int32_t *ctl = lacc + Kb + 1;                              // [k_next, accepted row or -1, live]
     double *gft = pa.ft + (size_t)rep * qpad, *gwft = pa.wft + (size_t)rep * qpad;
     double *rset = a.rset + (size_t)rep * N * P;
     double *cache = a.cache + (size_t)rep * a.cache_rows * qpad;
@@ -245,7 +250,6 @@ __global__ __launch_bounds__(256) void pipe_scan_kernel(const PipeArgs pa) {
     const double nqd = (double)a.nq;
 
     for (int i = tid; i < qpad; i += T) { lw[i] = a.w[i]; lwI[i] = a.wI[i]; }
-    if (tid == 0) { ctl[0] = 0; ctl[1] = 0; }
 
     // scanner-side chain state (meaningful in wave 0)
     FitResult cur{ch.A, ch.b, ch.chi2};
@@ -284,106 +288,170 @@ __global__ __launch_bounds__(256) void pipe_scan_kernel(const PipeArgs pa) {
         const int64_t w = (int64_t)t - sn.t_init - 1;
         const int64_t budget = a.max_iter - w * Kb;
         const int kmax_all = budget < Kb ? (budget < 0 ? 0 : (int)budget) : Kb;
-        const int nsub = (kmax_all + Ks - 1) / Ks;
+        const int ri0 = (int)((w * Kb) % N);
+        for (int i = tid; i < kmax_all * 4; i += T) ssub[i] = scal[i];
+        for (int i = tid; i < kmax_all; i += T) {
+            osub[i] = povf[i];
+            lstage[i] = stage[i];
+            int r = ri0 + i; if (r >= N) r -= N;
+            lslot[i] = slot_of[r];
+        }
+        if (tid == 0) lacc[Kb] = 0;
         const double invSw = 1.0 / a.Sw, SIoSw = a.SI / a.Sw, Scen = a.SII - a.SI * a.SI / a.Sw;
         double X = cur.chi2 * nqd;
         bool touched = false, live = true;
-        int ri = (int)((w * Kb) % N);
+        int num_acc_win = 0;
+        const bool dbg_noload = a.pad0 & 4, dbg_noscan = a.pad0 & 8;
         if (wave == 0) {
-            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(1);
             if (a.stop_flag && __hip_atomic_load(a.stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) stopped = 1;
+            if (lane == 0) ctl[2] = (!(cur.chi2 > a.conv_crit) || stopped) ? 0 : 1;   // `live`, shared by all waves
         }
-        __syncthreads();
-        for (int sw = 0; sw <= nsub; ++sw) {
-            const int sbuf = sw & 1;
-            if (wave > 0 && sw < nsub) {
-                // loaders: sub-window sw -> LDS (rows are 8*qpad bytes, contiguous)
-                const int kbeg = sw * Ks, kend = min(kmax_all, kbeg + Ks);
-                const int rows = kend - kbeg;
-                const double *src = dwin + (size_t)kbeg * qpad;
-                double *dst = dsub + (size_t)sbuf * Ks * qpad;
-                for (int i = tid - WAVE; i < rows * qpad; i += NL * WAVE) dst[i] = src[i];
-                for (int i = tid - WAVE; i < rows * 4; i += NL * WAVE) ssub[sbuf * Ks * 4 + i] = scal[kbeg * 4 + i];
-                for (int i = tid - WAVE; i < rows; i += NL * WAVE) osub[sbuf * Ks + i] = povf[kbeg + i];
+        // ---- eight symmetric waves.  Wave v owns the window's rows r = v (mod 8): it streams them from
+        // HBM into its private LDS ring with LDS-DMA (PIPE_RING rows in flight, no registers), computes
+        // h = Σ (w ft) d for its row of the current group of eight steps, and wave 0 decides the group.
+        typedef __attribute__((address_space(3))) void *lds_vp;
+        typedef __attribute__((address_space(1))) const void *glb_vp;
+        constexpr int CALLS = (QPL >= 2) ? QPL / 2 : 1;        // 1 KB DMA calls per row (QPL = 1: half a call, 32 lanes)
+        const bool dma_lane = (QPL >= 2) || lane < 32;
+        auto issue_row = [&](int m) {                          // m-th row of this wave: r = wave + 8 m
+            const char *gsrc = reinterpret_cast<const char *>(dwin + (size_t)(wave + 8 * m) * qpad) + lane * 16;
+            double *ldst = ring + (size_t)(m % PIPE_RING) * qpad;
+            if (dma_lane) {
+#pragma unroll
+                for (int c = 0; c < CALLS; ++c)
+                    __builtin_amdgcn_global_load_lds((glb_vp)(gsrc + c * 1024), (lds_vp)(ldst + c * 128), 16, 0, 0);
             }
-            if (wave == 0 && sw > 0 && live) {
-                const int pb = sbuf ^ 1;                      // sub-window sw-1
-                const int kbeg = (sw - 1) * Ks;
-                const int kmax = min(kmax_all, kbeg + Ks) - kbeg;
-                const double *dbase = dsub + (size_t)pb * Ks * qpad + lane;
-                const double *sbase = ssub + pb * Ks * 4;
-                const int32_t *obase = osub + pb * Ks;
-                const int g = lane & 7;
-                int k = 0;
-                if (!(cur.chi2 > a.conv_crit) || stopped) { live = false; k = kmax; }
-                while (k < kmax) {
-                    const int gcount = (kmax - k) < 8 ? (kmax - k) : 8;
-                    double acc[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+        };
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // prologue loads done before any DMA is counted
+        __builtin_amdgcn_s_barrier();
+        double wftr[QPL];
 #pragma unroll
-                    for (int j = 0; j < QPL; ++j) {
-                        const double wf = lwft[lane + WAVE * j];
+        for (int j = 0; j < QPL; ++j) wftr[j] = lwft[lane + WAVE * j];
+        const int my_rows = (kmax_all > wave) ? (kmax_all - wave + 7) / 8 : 0;   // rows this wave owns
+        int m_issue = 0, m_cur = 0;
+        if (!dbg_noload)
+            for (; m_issue < PIPE_RING && m_issue < my_rows; ++m_issue) issue_row(m_issue);
+        int k = 0;
+        live = ctl[2] != 0;
+        if (dbg_noscan) { num_iter += kmax_all; k = kmax_all; }
+        const int g = lane & 7;
+        while (k < kmax_all && live) {
+            const int gcount = (kmax_all - k) < 8 ? (kmax_all - k) : 8;
+            // my row of this group (if any): the smallest r >= k with r = wave (mod 8)
+            const int r = k + ((wave - (k & 7) + 8) & 7);
+            const int m = r >> 3;
+            const bool mine = r < k + gcount;
+            // retire rows behind the group start and refill the ring
+            while (m_cur < m) {
+                ++m_cur;
+                if (m_issue < my_rows && !dbg_noload) { issue_row(m_issue); ++m_issue; }
+            }
+            if (mine) {
+                // wait until row m has landed: only the DMAs of younger rows may still be in flight
+                const int younger = m_issue - 1 - m;
+                if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CALLS) : "memory");
+                else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CALLS) : "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CALLS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const double *dr = ring + (size_t)(m % PIPE_RING) * qpad + lane;
+                double h0 = 0., h1 = 0.;
 #pragma unroll
-                        for (int gg = 0; gg < 8; ++gg) {
-                            const int kk = (k + gg < Ks) ? k + gg : Ks - 1;
-                            const int slot = ((gg & 1) << 2) | (gg & 2) | ((gg >> 2) & 1);
-                            acc[slot] = fma(wf, dbase[(size_t)kk * qpad + WAVE * j], acc[slot]);
-                        }
-                    }
-                    const double h = wave_sum8_transposed(acc, lane);
-                    const int kg = (k + g < Ks) ? k + g : Ks - 1;
-                    const double *sc = sbase + kg * 4;
-                    const double SCt = SC + sc[0], SICt = SIC + sc[1], SCCt = SCC + (2. * h + sc[2]);
-                    double S = a.SII, num = SICt, den = SCCt;
-                    if (a.find_bg) {
-                        const double numc = SICt - SIoSw * SCt, denc = SCCt - SCt * invSw * SCt;
-                        const bool neg_b = a.pos_bg && (a.SI * denc - numc * SCt < 0.);
-                        if (!neg_b) { S = Scen; num = numc; den = denc; }
-                    }
-                    const bool acc_g = (g < gcount) && (num * num > (S - X) * den);
-                    const unsigned amask = (unsigned)(__ballot(acc_g) & 0xFFull);
-                    const unsigned ovm = (unsigned)(__ballot((g < gcount) && obase[kg]) & 0xFFull);
-                    if (amask == 0u) {
-                        if (ovm) overflow = 1;
-                        k += gcount; num_iter += gcount;
-                        ri += gcount; if (ri >= N) ri -= N;
-                        continue;
-                    }
+                for (int j = 0; j < QPL; j += 2) {
+                    h0 = fma(wftr[j], dr[WAVE * j], h0);
+                    if (j + 1 < QPL) h1 = fma(wftr[j + 1], dr[WAVE * (j + 1)], h1);
+                }
+                const double h = wave_sum(h0 + h1);
+                if (lane == 0) hbuf[r - k] = h;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                  // B1: hbuf complete
+            if (wave == 0) {
+                // lane g decides step k+g (all octets of lanes do the same work)
+                const int kg = (k + g < kmax_all) ? k + g : kmax_all - 1;
+                const double h = hbuf[g];
+                const double *sc = ssub + kg * 4;
+                const double SCt = SC + sc[0], SICt = SIC + sc[1], SCCt = SCC + (2. * h + sc[2]);
+                // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
+                double S = a.SII, num = SICt, den = SCCt;
+                if (a.find_bg) {
+                    const double numc = SICt - SIoSw * SCt, denc = SCCt - SCt * invSw * SCt;
+                    const bool neg_b = a.pos_bg && (a.SI * denc - numc * SCt < 0.);
+                    if (!neg_b) { S = Scen; num = numc; den = denc; }
+                }
+                const bool acc_g = (g < gcount) && (num * num > (S - X) * den);   // chi²_t < chi² (mcsas.py:379)
+                unsigned amask = (unsigned)(__ballot(acc_g) & 0xFFull);
+                if (a.pad0 & 32) amask = 0u;                        // diagnostic: never accept
+                const unsigned ovm = (unsigned)(__ballot((g < gcount) && osub[kg]) & 0xFFull);
+                int k_next, acc_row = -1;
+                if (amask == 0u) {
+                    if (ovm) overflow = 1;
+                    k_next = k + gcount; num_iter += gcount;
+                } else {
                     const int ga = __builtin_ctz(amask);
                     if (ovm & ((2u << ga) - 1u)) overflow = 1;
-                    const int ka = k + ga;
-                    int ria = ri + ga; if (ria >= N) ria -= N;
-                    {
-                        const double *dr = dbase + (size_t)ka * qpad;
-                        double fo[QPL], wv[QPL], dl[QPL];
-#pragma unroll
-                        for (int j = 0; j < QPL; ++j) { fo[j] = lft[lane + WAVE * j]; wv[j] = lw[lane + WAVE * j]; dl[j] = dr[WAVE * j]; }
-#pragma unroll
-                        for (int j = 0; j < QPL; ++j) {
-                            const double f = fo[j] + dl[j];
-                            lft[lane + WAVE * j] = f;
-                            lwft[lane + WAVE * j] = wv[j] * f;
-                        }
-                    }
+                    acc_row = k + ga;
                     SC = readlane_f64(SCt, ga); SIC = readlane_f64(SICt, ga); SCC = readlane_f64(SCCt, ga);
                     cur = solve_fit(a, SC, SCC, SIC);
                     X = cur.chi2 * nqd;
-                    {
-                        const int kglob = kbeg + ka;
-                        const int fresh = stage[kglob];
-                        const int freed = slot_of[ria];
-                        if (lane == 0) {
-                            slot_of[ria] = fresh; stage[kglob] = freed;
-                            for (int p = 0; p < P; ++p) rset[(size_t)ria * P + p] = pval[(size_t)kglob * MCSAS_MAX_ACTIVE + p];
-                        }
+                    const int fresh = lstage[acc_row], freed = lslot[acc_row];
+                    if (lane == 0) {
+                        lslot[acc_row] = fresh; lstage[acc_row] = freed;      // slot swap: rows are never copied
+                        lacc[num_acc_win] = acc_row;
                     }
-                    ++num_moves;
+                    ++num_acc_win; ++num_moves;
                     touched = true;
-                    k = ka + 1; num_iter += ga + 1;
-                    ri = ria + 1; if (ri >= N) ri -= N;
-                    if (!(cur.chi2 > a.conv_crit)) { live = false; break; }
+                    k_next = acc_row + 1; num_iter += ga + 1;
+                    if (!(cur.chi2 > a.conv_crit)) live = false;
+                }
+                if (lane == 0) { ctl[0] = k_next; ctl[1] = acc_row; ctl[2] = live ? 1 : 0; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                  // B2: decision published
+            const int k_next = ctl[0], acc_row = ctl[1];
+            live = ctl[2] != 0;
+            if (acc_row >= 0) {
+                if ((acc_row & 7) == wave) {
+                    // the owner of the accepted row applies it: ft += d, w ft refreshed (mcsas.py:381-382)
+                    const double *dr = ring + (size_t)((acc_row >> 3) % PIPE_RING) * qpad;
+                    double fo[QPL], dv[QPL], wv[QPL];
+#pragma unroll
+                    for (int j = 0; j < QPL; ++j) {              // all LDS reads first, then the writes
+                        const int i = lane + WAVE * j;
+                        fo[j] = lft[i]; dv[j] = dr[i]; wv[j] = lw[i];
+                    }
+#pragma unroll
+                    for (int j = 0; j < QPL; ++j) {
+                        const int i = lane + WAVE * j;
+                        const double f = fo[j] + dv[j];
+                        lft[i] = f; lwft[i] = wv[j] * f;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                              // B3: new ft visible
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) wftr[j] = lwft[lane + WAVE * j];
+            }
+            k = k_next;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // no DMA may outlive the ring
+        if (wave == 0 && lane == 0) lacc[Kb] = num_acc_win;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        {   // write the window's slot tables back and store the accepted proposals (mcsas.py:381), all waves
+            const int nacc = lacc[Kb];
+            if (nacc > 0) {
+                for (int i = tid; i < kmax_all; i += T) {
+                    stage[i] = lstage[i];
+                    int r = ri0 + i; if (r >= N) r -= N;
+                    slot_of[r] = lslot[i];
+                }
+                for (int i = tid; i < nacc * P; i += T) {
+                    const int kk = lacc[i / P], p = i % P;
+                    int r = ri0 + kk; if (r >= N) r -= N;
+                    rset[(size_t)r * P + p] = pval[(size_t)kk * MCSAS_MAX_ACTIVE + p];
                 }
             }
-            __syncthreads();
         }
         if (wave == 0) {
             if (touched) {
@@ -466,6 +534,20 @@ __global__ __launch_bounds__(256) void pipe_scan_kernel(const PipeArgs pa) {
                 __hip_atomic_fetch_add(pa.n_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------ one tick
+// launch t: blocks [0, R) do SCAN(t) (skipped for t < 0), the others PROD(t + 1)
+template <int M, int QPL>
+__global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs pa) {
+    extern __shared__ double lds[];
+    const int R = pa.c.n_reps, b = blockIdx.x, t = pa.tick;
+    if (b < R) {
+        if (t >= 0) pipe_scan_block<QPL>(pa, lds, b, t);
+    } else {
+        const int gy = pa.g.prod_blocks_y;
+        pipe_prod_block<M, QPL>(pa, lds, (b - R) / gy, (b - R) % gy, gy, t + 1);
     }
 }
 

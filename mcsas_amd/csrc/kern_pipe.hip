@@ -1,5 +1,5 @@
-// kern_pipe.hip — instantiates the pipeline producer for ONE model (-DMCSAS_M=<id>) and, for
-// model 0 only, the model-independent scan/reset kernels.
+// kern_pipe.hip — instantiates the pipeline tick kernel for ONE model (-DMCSAS_M=<id>) and, for
+// model 0 only, the model-independent reset kernel.
 #include "chain_pipe.h"
 #ifndef MCSAS_M
 #error "compile with -DMCSAS_M=<model id>"
@@ -8,26 +8,16 @@
 #define CAT(a, b) CAT_(a, b)
 using namespace mcsas;
 
-void *CAT(mcsas_pipe_prod_kernel_m, MCSAS_M)(int qpl) {
+void *CAT(mcsas_pipe_tick_kernel_m, MCSAS_M)(int qpl) {
     switch (qpl) {
-        case 1: return (void *)pipe_prod_kernel<MCSAS_M, 1>;
-        case 2: return (void *)pipe_prod_kernel<MCSAS_M, 2>;
-        case 4: return (void *)pipe_prod_kernel<MCSAS_M, 4>;
-        case 8: return (void *)pipe_prod_kernel<MCSAS_M, 8>;
-        case 16: return (void *)pipe_prod_kernel<MCSAS_M, 16>;
+        case 1: return (void *)pipe_tick_kernel<MCSAS_M, 1>;
+        case 2: return (void *)pipe_tick_kernel<MCSAS_M, 2>;
+        case 4: return (void *)pipe_tick_kernel<MCSAS_M, 4>;
+        case 8: return (void *)pipe_tick_kernel<MCSAS_M, 8>;
+        case 16: return (void *)pipe_tick_kernel<MCSAS_M, 16>;
         default: return nullptr;
     }
 }
 #if MCSAS_M == 0
-void *mcsas_pipe_scan_kernel(int qpl) {
-    switch (qpl) {
-        case 1: return (void *)pipe_scan_kernel<1>;
-        case 2: return (void *)pipe_scan_kernel<2>;
-        case 4: return (void *)pipe_scan_kernel<4>;
-        case 8: return (void *)pipe_scan_kernel<8>;
-        case 16: return (void *)pipe_scan_kernel<16>;
-        default: return nullptr;
-    }
-}
 void *mcsas_pipe_reset_kernel() { return (void *)pipe_reset_kernel<0>; }
 #endif

@@ -188,16 +188,16 @@ struct mcsas_plan {
 void *mcsas_wave_kernel_m0(int, bool); void *mcsas_wave_kernel_m1(int, bool);
 void *mcsas_wave_kernel_m2(int, bool); void *mcsas_wave_kernel_m3(int, bool);
 void *mcsas_wg_kernel_m0(int); void *mcsas_wg_kernel_m1(int); void *mcsas_wg_kernel_m2(int); void *mcsas_wg_kernel_m3(int);
-void *mcsas_pipe_prod_kernel_m0(int); void *mcsas_pipe_prod_kernel_m1(int);
-void *mcsas_pipe_prod_kernel_m2(int); void *mcsas_pipe_prod_kernel_m3(int);
-void *mcsas_pipe_scan_kernel(int); void *mcsas_pipe_reset_kernel();
+void *mcsas_pipe_tick_kernel_m0(int); void *mcsas_pipe_tick_kernel_m1(int);
+void *mcsas_pipe_tick_kernel_m2(int); void *mcsas_pipe_tick_kernel_m3(int);
+void *mcsas_pipe_reset_kernel();
 
-static void *pipe_prod_kernel_for(int model, int qpl) {
+static void *pipe_tick_kernel_for(int model, int qpl) {
     switch (model) {
-        case MCSAS_MODEL_SPHERE: return mcsas_pipe_prod_kernel_m0(qpl);
-        case MCSAS_MODEL_CYL_ISO: return mcsas_pipe_prod_kernel_m1(qpl);
-        case MCSAS_MODEL_ELL_CS: return mcsas_pipe_prod_kernel_m2(qpl);
-        case MCSAS_MODEL_KHOLODENKO: return mcsas_pipe_prod_kernel_m3(qpl);
+        case MCSAS_MODEL_SPHERE: return mcsas_pipe_tick_kernel_m0(qpl);
+        case MCSAS_MODEL_CYL_ISO: return mcsas_pipe_tick_kernel_m1(qpl);
+        case MCSAS_MODEL_ELL_CS: return mcsas_pipe_tick_kernel_m2(qpl);
+        case MCSAS_MODEL_KHOLODENKO: return mcsas_pipe_tick_kernel_m3(qpl);
         default: return nullptr;
     }
 }
@@ -392,12 +392,8 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         *pl->h_done = 0;
         int32_t *d_done = nullptr;
         PCHK(hipHostGetDevicePointer((void **)&d_done, pl->h_done, 0));
-        PCHK(hipStreamCreateWithFlags(&pl->sP, hipStreamNonBlocking));
-        PCHK(hipStreamCreateWithFlags(&pl->sS, hipStreamNonBlocking));
-        for (int i = 0; i < mcsas_plan::RING; ++i) {
-            PCHK(hipEventCreateWithFlags(&pl->evP[i], hipEventDisableTiming));
+        for (int i = 0; i < mcsas_plan::RING; ++i)
             PCHK(hipEventCreateWithFlags(&pl->evS[i], hipEventDisableTiming));
-        }
         pa.c = a;
         pa.chains = pl->d_chains; pa.ft = pl->d_ft; pa.wft = pl->d_wft; pa.slot_of = pl->d_slot_of;
         pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.scal = pl->d_scal; pa.pval = pl->d_pval;
@@ -419,49 +415,36 @@ extern "C" int mcsas_hip_plan_reseed(mcsas_plan *pl, uint64_t seed, int32_t rep_
 static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     PipeArgs &pa = pl->pipe;
     pa.c = pl->args;                                     // picks up reseed()
+    pa.c.cache_rows = pl->args.cache_rows;
     const int R = pl->prob.n_reps, Kb = pa.g.kb;
-    void *prod = pipe_prod_kernel_for(pl->prob.model_id, pl->qpl), *scan = mcsas_pipe_scan_kernel(pl->qpl);
-    void *reset = mcsas_pipe_reset_kernel();
-    if (!prod || !scan) return fail(MCSAS_EINVAL, "no pipeline kernel for model %d qpl %d", pl->prob.model_id, pl->qpl);
-    if (pa.g.prod_lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(prod, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pa.g.prod_lds));
-    if (pa.g.scan_lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pa.g.scan_lds));
+    void *tick = pipe_tick_kernel_for(pl->prob.model_id, pl->qpl), *reset = mcsas_pipe_reset_kernel();
+    if (!tick) return fail(MCSAS_EINVAL, "no pipeline kernel for model %d qpl %d", pl->prob.model_id, pl->qpl);
+    const size_t lds = std::max(pa.g.prod_lds, pa.g.scan_lds);
+    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(tick, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     *pl->h_done = 0;
     HIPCHK(hipEventRecord(pl->ev0, st));
-    HIPCHK(hipStreamWaitEvent(pl->sS, pl->ev0, 0));
     {
         void *ka[] = {(void *)&pa};
-        HIPCHK(hipLaunchKernel(reset, dim3((R + 63) / 64), dim3(64), ka, 0, pl->sS));
+        HIPCHK(hipLaunchKernel(reset, dim3((R + 63) / 64), dim3(64), ka, 0, st));
     }
-    HIPCHK(hipEventRecord(pl->evS[mcsas_plan::RING - 1], pl->sS));
-    HIPCHK(hipStreamWaitEvent(pl->sP, pl->evS[mcsas_plan::RING - 1], 0));
     // worst case: every attempt runs to max_iter
     const long long win_per_attempt = (long long)((pl->prob.max_iter + Kb - 1) / Kb) + 3;
     const long long max_ticks = std::min<long long>((long long)(pl->prob.max_retries + 1) * win_per_attempt + 4, 2000000000LL);
-    const dim3 pgrid(R, pa.g.prod_blocks_y), sgrid(R);
-    int t = 0;
+    const dim3 grid(R + R * pa.g.prod_blocks_y);
+    long long t = -1;                                    // launch t = {SCAN(t), PROD(t+1)}
     for (; t < max_ticks; ++t) {
-        const int r = t % mcsas_plan::RING;
-        if (t >= mcsas_plan::RING / 2 && (t % 8) == 0) {
-            // throttle: stay at most RING/2 ticks ahead of the GPU, forward the stop word, leave when all chains are done
-            HIPCHK(hipEventSynchronize(pl->evS[(t - mcsas_plan::RING / 2) % mcsas_plan::RING]));
+        if (t >= mcsas_plan::RING && (t % 16) == 0) {
+            // throttle: stay at most ~RING ticks ahead of the GPU, forward the stop word, leave when all chains are done
+            HIPCHK(hipEventSynchronize(pl->evS[((t - mcsas_plan::RING) / 16) % mcsas_plan::RING]));
             if (pl->prob.stop && *pl->prob.stop) *pl->h_stop = 1;
             if (*(volatile int32_t *)pl->h_done >= R) break;
         }
-        pa.tick = t;
+        pa.tick = (int32_t)t;
         void *ka[] = {(void *)&pa};
-        if (t >= 2) HIPCHK(hipStreamWaitEvent(pl->sP, pl->evS[(t - 2) % mcsas_plan::RING], 0));
-        HIPCHK(hipLaunchKernel(prod, pgrid, dim3(256), ka, pa.g.prod_lds, pl->sP));
-        HIPCHK(hipEventRecord(pl->evP[r], pl->sP));
-        HIPCHK(hipStreamWaitEvent(pl->sS, pl->evP[r], 0));
-        HIPCHK(hipLaunchKernel(scan, sgrid, dim3(64 * pa.g.scan_waves), ka, pa.g.scan_lds, pl->sS));
-        HIPCHK(hipEventRecord(pl->evS[r], pl->sS));
+        HIPCHK(hipLaunchKernel(tick, grid, dim3(PIPE_BLOCK), ka, lds, st));
+        if (t >= 0 && (t % 16) == 0) HIPCHK(hipEventRecord(pl->evS[(t / 16) % mcsas_plan::RING], st));
     }
-    pl->ticks_launched = t;
-    // join both internal streams back into the caller's stream
-    HIPCHK(hipEventRecord(pl->evP[mcsas_plan::RING - 1], pl->sP));
-    HIPCHK(hipEventRecord(pl->evS[mcsas_plan::RING - 2], pl->sS));
-    HIPCHK(hipStreamWaitEvent(st, pl->evP[mcsas_plan::RING - 1], 0));
-    HIPCHK(hipStreamWaitEvent(st, pl->evS[mcsas_plan::RING - 2], 0));
+    pl->ticks_launched = (int)t;
     HIPCHK(hipEventRecord(pl->ev1, st));
     return MCSAS_OK;
 }
