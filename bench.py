@@ -139,18 +139,25 @@ def main():
     if rank == 0:
         launch_s = kernel_ms * 1e-3 / args.steps
         achieved = BYTES_PER_MC_STEP * (mc_steps / args.steps) / launch_s
+        # HBM-side bytes per MC step from the committed PMC passes of this same command
+        # (profiles/r01_pmc_summary.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); pipeline mode only
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if plan.info["exec_mode"] == "pipeline" and os.path.exists(tj):
+            pm = json.load(open(tj))
+            traffic = (pm["fetch_bytes_per_mc_step"] + pm["write_bytes_per_mc_step"]) * (mc_steps / args.steps) / launch_s / 1e9
         out = {
             "metric": "MC accept/reject steps/sec (whole node)", "value": total_steps / dt, "unit": "MC steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Sphere, synthetic %d q-points x %d contribs, %d reps/GPU, %d MC steps per chain per launch, convergenceCriterion=0"
                                    % (Q, NCONTRIB, args.reps, args.mc_steps),
-                       "reps_total": n_total, "waves_per_chain": plan.prob.c.waves_per_chain or 1},
+                       "reps_total": n_total, **plan.info},
             "final_chisq_median": float(np.median(res.chisq)),
             "kernel_ms_per_launch": launch_s * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
-                         "note": "achieved = 40*Q B per MC step (SURVEY 8d streaming model) x MC steps per launch / HIP-event kernel time"},
+                         "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "note": "achieved = 40*Q B per MC step (SURVEY 8d streaming model, chain state actually stays on chip) x MC steps per launch / HIP-event time of the launch sequence"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(q, I, sigma, lo, hi)

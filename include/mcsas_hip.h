@@ -148,6 +148,10 @@ int  mcsas_hip_plan_fetch(mcsas_plan *plan, mcsas_result *result);
 int  mcsas_hip_plan_last_ms(mcsas_plan *plan, double *ms);
 /* total MC steps executed by the last launch (sum of iterations over chains and attempts) */
 int  mcsas_hip_plan_total_steps(mcsas_plan *plan, int64_t *steps);
+/* how the plan executes: info[0] = exec mode chosen (MCSAS_EXEC_*), [1] = waves per chain, [2] = q slots
+ * per lane, [3] = speculative window (steps), [4] = kernel launches of the last mcsas_hip_plan_launch,
+ * [5] = 1 if per-contribution intensity rows are cached in HBM, [6..7] reserved */
+int  mcsas_hip_plan_info(mcsas_plan *plan, int32_t info[8]);
 /* change seed / rep_offset between launches without re-uploading anything else */
 int  mcsas_hip_plan_reseed(mcsas_plan *plan, uint64_t seed, int32_t rep_offset);
 void mcsas_hip_plan_destroy(mcsas_plan *plan);

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libm
 # every symbol include/mcsas_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "mcsas_hip_analyse", "mcsas_hip_plan_create", "mcsas_hip_plan_launch", "mcsas_hip_plan_fetch",
-    "mcsas_hip_plan_last_ms", "mcsas_hip_plan_total_steps", "mcsas_hip_plan_reseed",
+    "mcsas_hip_plan_last_ms", "mcsas_hip_plan_total_steps", "mcsas_hip_plan_reseed", "mcsas_hip_plan_info",
     "mcsas_hip_plan_destroy", "mcsas_hip_model_calc", "mcsas_hip_bgfit", "mcsas_hip_observability",
     "mcsas_hip_device_count", "mcsas_hip_abi_version", "mcsas_hip_last_error",
 )
@@ -99,6 +99,7 @@ def load():
     lib.mcsas_hip_plan_last_ms.argtypes = [C.c_void_p, _dp]
     lib.mcsas_hip_plan_total_steps.argtypes = [C.c_void_p, _i64p]
     lib.mcsas_hip_plan_reseed.argtypes = [C.c_void_p, C.c_uint64, C.c_int32]
+    lib.mcsas_hip_plan_info.argtypes = [C.c_void_p, _i32p]
     lib.mcsas_hip_plan_destroy.argtypes = [C.c_void_p]
     lib.mcsas_hip_plan_destroy.restype = None
     lib.mcsas_hip_model_calc.argtypes = [C.POINTER(Problem), _dp, C.c_int32, _dp, _dp, _dp, _dp, _dp]

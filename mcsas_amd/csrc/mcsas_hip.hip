@@ -539,6 +539,16 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
     return MCSAS_OK;
 }
 
+extern "C" int mcsas_hip_plan_info(mcsas_plan *pl, int32_t info[8]) {
+    if (!pl || !info) return fail(MCSAS_EINVAL, "null argument");
+    memset(info, 0, sizeof(int32_t) * 8);
+    info[0] = pl->mode; info[1] = pl->waves; info[2] = pl->qpl;
+    info[3] = pl->mode == MCSAS_EXEC_PIPELINE ? pl->pipe.g.kb : (pl->mode == MCSAS_EXEC_WORKGROUP ? pl->wg.window : 1);
+    info[4] = pl->mode == MCSAS_EXEC_PIPELINE ? pl->ticks_launched + 2 : 1;
+    info[5] = pl->use_cache;
+    return MCSAS_OK;
+}
+
 extern "C" int mcsas_hip_plan_last_ms(mcsas_plan *pl, double *ms) {
     if (!pl || !ms) return fail(MCSAS_EINVAL, "null argument");
     *ms = pl->last_ms;

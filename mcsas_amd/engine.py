@@ -170,6 +170,15 @@ class Plan:
         check(self.lib.mcsas_hip_plan_reseed(self.h, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_int32(rep_offset)))
 
     @property
+    def info(self):
+        """dict: exec mode the library chose, waves per chain, q slots per lane, window, launches, cache."""
+        v = (C.c_int32 * 8)()
+        check(self.lib.mcsas_hip_plan_info(self.h, v))
+        names = {1: "wave", 2: "workgroup", 3: "pipeline"}
+        return dict(exec_mode=names.get(v[0], str(v[0])), waves_per_chain=v[1], q_per_lane=v[2], window=v[3],
+                    launches=v[4], cached_rows=bool(v[5]))
+
+    @property
     def last_ms(self):
         v = C.c_double()
         check(self.lib.mcsas_hip_plan_last_ms(self.h, C.byref(v)))
