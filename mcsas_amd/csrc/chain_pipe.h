@@ -43,6 +43,7 @@ struct PipeGeom {
     int32_t prod_blocks_y;        // producer grid.y
     int32_t scan_waves;           // scan kernel waves (1 scanner + loaders)
     int32_t qpl;
+    int32_t ring, pad;            // rows each scan wave keeps in its private LDS ring (4, 2 or 1)
     uint64_t prod_lds, scan_lds;
 };
 
@@ -63,7 +64,7 @@ struct PipeArgs {
 };
 
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
-constexpr int PIPE_RING = 4;         // rows each scan wave keeps in flight / in its private LDS ring
+constexpr int PIPE_RING = 4;         // most rows a scan wave keeps in flight in its private LDS ring
 
 static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, PipeGeom *g) {
     int qpl = 1;
@@ -80,10 +81,14 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, PipeGeom
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
     g->prod_lds = sizeof(double) * (4 * (size_t)qpad + tab_doubles);
-    // scan block LDS: w, wI, ft, wft + one private ring of PIPE_RING rows per wave + the window's scalars/tables
+    // scan block LDS: w, wI, ft, wft + one private ring of `ring` rows per wave + the window's scalars/tables
     g->ks = 8; g->scan_waves = PIPE_BLOCK / 64;
-    g->scan_lds = sizeof(double) * ((4 + (size_t)g->scan_waves * PIPE_RING) * qpad + (size_t)g->kb * 4 + 16)
-                + sizeof(int32_t) * (4 * g->kb + 32) + 64;
+    for (int ring = PIPE_RING; ring >= 1; ring /= 2) {
+        g->ring = ring;
+        g->scan_lds = sizeof(double) * ((4 + (size_t)g->scan_waves * ring) * qpad + (size_t)g->kb * 4 + 16)
+                    + sizeof(int32_t) * (4 * g->kb + 32) + 64;
+        if (g->scan_lds <= 160 * 1024) break;
+    }
     if (g->scan_lds > 160 * 1024) return 1;
     return 0;
 }
@@ -230,8 +235,9 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
     const PipeSnap sn = ch.snap[(t + 1) & 1];                 // the record in force for tick t (written at t-1; host for t = 0)
 
     double *lw = lds, *lwI = lds + qpad, *lft = lds + 2 * qpad, *lwft = lds + 3 * qpad;
-    double *ring = lds + (4 + (size_t)wave * PIPE_RING) * qpad;            // this wave's PIPE_RING rows
-    double *ssub = lds + (4 + (size_t)NW * PIPE_RING) * qpad;              // [Kb][4] scalars of the whole window
+    const int RING = pa.g.ring;
+    double *ring = lds + (4 + (size_t)wave * RING) * qpad;                 // this wave's RING rows
+    double *ssub = lds + (4 + (size_t)NW * RING) * qpad;                   // [Kb][4] scalars of the whole window
     double *hbuf = ssub + (size_t)Kb * 4;                                  // [8] h of the current group, by step offset
     int32_t *osub = reinterpret_cast<int32_t *>(hbuf + 16);                // [Kb] replay-overflow flags
     int32_t *lstage = osub + Kb, *lslot = lstage + Kb;          // [Kb] spare row slot of step k / row slot of its contribution
@@ -316,7 +322,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         const bool dma_lane = (QPL >= 2) || lane < 32;
         auto issue_row = [&](int m) {                          // m-th row of this wave: r = wave + 8 m
             const char *gsrc = reinterpret_cast<const char *>(dwin + (size_t)(wave + 8 * m) * qpad) + lane * 16;
-            double *ldst = ring + (size_t)(m % PIPE_RING) * qpad;
+            double *ldst = ring + (size_t)(m % RING) * qpad;
             if (dma_lane) {
 #pragma unroll
                 for (int c = 0; c < CALLS; ++c)
@@ -331,7 +337,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         const int my_rows = (kmax_all > wave) ? (kmax_all - wave + 7) / 8 : 0;   // rows this wave owns
         int m_issue = 0, m_cur = 0;
         if (!dbg_noload)
-            for (; m_issue < PIPE_RING && m_issue < my_rows; ++m_issue) issue_row(m_issue);
+            for (; m_issue < RING && m_issue < my_rows; ++m_issue) issue_row(m_issue);
         int k = 0;
         live = ctl[2] != 0;
         if (dbg_noscan) { num_iter += kmax_all; k = kmax_all; }
@@ -354,7 +360,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CALLS) : "memory");
                 else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CALLS) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const double *dr = ring + (size_t)(m % PIPE_RING) * qpad + lane;
+                const double *dr = ring + (size_t)(m % RING) * qpad + lane;
                 double h0 = 0., h1 = 0.;
 #pragma unroll
                 for (int j = 0; j < QPL; j += 2) {
@@ -413,7 +419,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             if (acc_row >= 0) {
                 if ((acc_row & 7) == wave) {
                     // the owner of the accepted row applies it: ft += d, w ft refreshed (mcsas.py:381-382)
-                    const double *dr = ring + (size_t)((acc_row >> 3) % PIPE_RING) * qpad;
+                    const double *dr = ring + (size_t)((acc_row >> 3) % RING) * qpad;
                     double fo[QPL], dv[QPL], wv[QPL];
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {              // all LDS reads first, then the writes

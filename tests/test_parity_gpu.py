@@ -238,3 +238,56 @@ def test_sasfit_kholodenko_known_answer_on_gpu(golden_dir):
     m, _ = make_models("kholodenko")
     cum, v, w, s = engine.model_calc(m.setup(), q, [[1.0, 10.0, 1000.0]], 0.0)
     assert np.mean(np.abs((Iref - cum) / Iref)) < 1e-5
+
+
+def _synthetic(nq):
+    from bench import synthetic_data
+    return synthetic_data(nq)
+
+
+FULL = {
+    # BASELINE.json configs 3-5 at their full q x contribution sizes; repetitions and step budgets cut so
+    # the GPU suite stays short (the form factors of these models cost 100-1000x a sphere's)
+    "cfg3_cylinders": dict(tag="cyl_aspect", nq=512, n=400, lo=[1e-9, 0.5], hi=[1e-7, 20.0], reps=6, steps=(40, 160)),
+    "cfg4_ellipsoid": dict(tag="ellcs", nq=1024, n=1000, lo=[1e-9, 2e-9, 2e-10], hi=[1e-7, 2e-7, 1e-8], reps=4, steps=(30, 120)),
+    "cfg5_kholodenko": dict(tag="kholodenko", nq=512, n=600, lo=None, hi=None, reps=3, steps=(16, 48)),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL))
+def test_full_size_properties_other_configs(name):
+    """Size-independent properties at the full BASELINE shapes: (1) the three execution modes (wavefront
+    / workgroup / whole-chip pipeline) give IDENTICAL chains, (2) chi² never increases with the step
+    budget on the same stream, (3) the reported chi² equals a direct evaluation of the reported fit,
+    (4) parameters stay inside their generator ranges."""
+    c = FULL[name]
+    q, I, sig = _synthetic(c["nq"])
+    m, _ = make_models(c["tag"], c["lo"], c["hi"])
+    setup = m.setup()
+    prev = None
+    for steps in c["steps"]:
+        res = {}
+        for mode in (engine.EXEC_PIPELINE, engine.EXEC_WAVE, engine.EXEC_WORKGROUP):
+            if mode != engine.EXEC_PIPELINE and steps != c["steps"][0]:
+                continue                                  # cross-mode identity on the short budget only
+            st = engine.Settings(n_contrib=c["n"], n_reps=c["reps"], max_iter=steps, conv_crit=0.0, max_retries=0,
+                                 seed=11, exec_mode=mode)
+            try:
+                res[mode] = engine.analyse(setup, q, I, sig, st)
+            except mcsas_amd._lib.McSASHipError as e:
+                if mode == engine.EXEC_PIPELINE:
+                    raise
+                assert e.code == -1                       # a mode that does not fit this shape says so
+        r = res[engine.EXEC_PIPELINE]
+        for mode, o in res.items():
+            np.testing.assert_array_equal(o.num_moves, r.num_moves)
+            np.testing.assert_array_equal(o.contribs, r.contribs)
+            np.testing.assert_allclose(o.chisq, r.chisq, rtol=1e-9)
+        assert (r.num_iter == steps).all()
+        direct = (((I[:, None] - r.fit) / sig[:, None])**2).sum(axis=0) / len(q)
+        np.testing.assert_allclose(r.chisq, direct, rtol=1e-9)
+        for col in range(setup.n_active):
+            assert (r.contribs[:, col, :] >= setup.gen_lo[col]).all() and (r.contribs[:, col, :] <= setup.gen_hi[col]).all()
+        if prev is not None:
+            assert (r.chisq <= prev * (1 + 1e-12)).all()
+        prev = r.chisq.copy()
