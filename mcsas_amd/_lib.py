@@ -15,7 +15,8 @@ MAX_ACTIVE = 4
 MAX_PARAMS = 8
 ABI_VERSION = 1
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmcsas_hip.so")
+# MCSAS_HIP_LIB selects another build of the SAME library (e.g. the -DMCSAS_STAMPS diagnostic build)
+LIB_PATH = os.environ.get("MCSAS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmcsas_hip.so")
 
 # every symbol include/mcsas_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = (

@@ -10,7 +10,22 @@ struct ChainOut {
     double  chisq, scaling, background, seconds;
     int64_t num_iter, num_moves, draws, total_steps;
     int32_t attempts, converged, stream_overflow, stopped;
+#ifdef MCSAS_STAMPS
+    int64_t dbg[16];         // diagnostic build only (make EXTRA=-DMCSAS_STAMPS): s_memtime sums per phase
+#endif
 };
+
+// In-kernel stamps (cdna_hip_programming.md §7): compiled in ONLY with -DMCSAS_STAMPS; such a build is
+// for reading phase SHARES, never for timing.
+#ifdef MCSAS_STAMPS
+#define MCSAS_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MCSAS_STAMP_DECL(...) uint64_t __VA_ARGS__
+#define MCSAS_STAMP_ADD(acc, t1, t0) (acc) += (int64_t)((t1) - (t0))
+#else
+#define MCSAS_STAMP(var) do { } while (0)
+#define MCSAS_STAMP_DECL(...)
+#define MCSAS_STAMP_ADD(acc, t1, t0) do { } while (0)
+#endif
 
 struct ChainArgs {
     ModelArgs model;

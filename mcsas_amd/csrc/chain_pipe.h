@@ -22,6 +22,10 @@
 
 namespace mcsas {
 
+// Keep a wave-uniform double in a VGPR: the scan loop has far more uniform fp64 state than the 102
+// SGPRs can hold, and spilled SGPRs come back one v_readlane at a time on the critical path.
+#define MCSAS_IN_VGPR(x) asm volatile("" : "+v"(x))
+
 struct PipeSnap {                 // what the producer needs to know about a chain
     int32_t attempt, t_init, alive, pad;
     uint64_t init_base;           // draw index of the initial parameter set of this attempt
@@ -34,6 +38,9 @@ struct PipeChain {                // per-chain scanner state, lives in HBM betwe
     int64_t num_iter, num_moves, total_steps;
     uint64_t draw_pos, t_start;
     int32_t attempts, converged, stopped, overflow, done, pad;
+#ifdef MCSAS_STAMPS
+    int64_t dbg[16];
+#endif
 };
 
 struct PipeGeom {
@@ -342,17 +349,31 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         live = ctl[2] != 0;
         if (dbg_noscan) { num_iter += kmax_all; k = kmax_all; }
         const int g = lane & 7;
+        // loop-invariant fit constants and the running sums, pinned in VGPRs (see MCSAS_IN_VGPR)
+        double cSII = a.SII, cSI = a.SI, cScen = Scen, cSIoSw = SIoSw, cinvSw = invSw, cCrit = a.conv_crit, cnq = nqd;
+        MCSAS_IN_VGPR(cSII); MCSAS_IN_VGPR(cSI); MCSAS_IN_VGPR(cScen); MCSAS_IN_VGPR(cSIoSw); MCSAS_IN_VGPR(cinvSw);
+        MCSAS_IN_VGPR(cCrit); MCSAS_IN_VGPR(cnq);
+        MCSAS_IN_VGPR(SC); MCSAS_IN_VGPR(SIC); MCSAS_IN_VGPR(SCC); MCSAS_IN_VGPR(X);
+        const bool find_bg = a.find_bg, pos_bg = a.pos_bg, never_accept = a.pad0 & 32;
+#ifdef MCSAS_STAMPS
+        int64_t ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+        MCSAS_STAMP_DECL(s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0, s8 = 0, s9 = 0);
         while (k < kmax_all && live) {
+            MCSAS_STAMP(s0);
             const int gcount = (kmax_all - k) < 8 ? (kmax_all - k) : 8;
             // my row of this group (if any): the smallest r >= k with r = wave (mod 8)
             const int r = k + ((wave - (k & 7) + 8) & 7);
             const int m = r >> 3;
             const bool mine = r < k + gcount;
-            // retire rows behind the group start and refill the ring
-            while (m_cur < m) {
+            // (rows behind the group start are normally retired and the ring refilled AFTER the barrier,
+            // while the decision is being taken, so the DMA issue costs the critical path nothing; only a
+            // ring too shallow to hold the next row has to catch up here)
+            while (mine && m_issue <= m && m_cur < m && !dbg_noload) {
                 ++m_cur;
-                if (m_issue < my_rows && !dbg_noload) { issue_row(m_issue); ++m_issue; }
+                if (m_issue < my_rows) { issue_row(m_issue); ++m_issue; }
             }
+            MCSAS_STAMP(s1);
             if (mine) {
                 // wait until row m has landed: only the DMAs of younger rows may still be in flight
                 const int younger = m_issue - 1 - m;
@@ -360,6 +381,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CALLS) : "memory");
                 else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CALLS) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MCSAS_STAMP(s2);
                 const double *dr = ring + (size_t)(m % RING) * qpad + lane;
                 double h0 = 0., h1 = 0.;
 #pragma unroll
@@ -367,28 +389,44 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     h0 = fma(wftr[j], dr[WAVE * j], h0);
                     if (j + 1 < QPL) h1 = fma(wftr[j + 1], dr[WAVE * (j + 1)], h1);
                 }
-                const double h = wave_sum(h0 + h1);
+                const double hs = h0 + h1;
+                MCSAS_STAMP(s3);
+                const double h = wave_sum(hs);
+                MCSAS_STAMP(s4);
                 if (lane == 0) hbuf[r - k] = h;
             }
+            // the scalars of my lane's step do not depend on the other waves: fetch them before the barrier
+            const int kg = (k + g < kmax_all) ? k + g : kmax_all - 1;
+            double sc0 = 0., sc1 = 0., sc2 = 0.;
+            int ovg = 0;
+            if (wave == 0) { const double *sc = ssub + kg * 4; sc0 = sc[0]; sc1 = sc[1]; sc2 = sc[2]; ovg = osub[kg]; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MCSAS_STAMP(s5);
             __builtin_amdgcn_s_barrier();                                  // B1: hbuf complete
+            MCSAS_STAMP(s6);
+            if (wave != 0) {
+                // workers: retire the rows behind this group's start and refill the ring while wave 0 decides
+                const int m_keep = (k + ((wave - (k & 7) + 8) & 7)) >> 3;   // my first row at or after k
+                while (m_cur < m_keep) {
+                    ++m_cur;
+                    if (m_issue < my_rows && !dbg_noload) { issue_row(m_issue); ++m_issue; }
+                }
+            }
             if (wave == 0) {
                 // lane g decides step k+g (all octets of lanes do the same work)
-                const int kg = (k + g < kmax_all) ? k + g : kmax_all - 1;
                 const double h = hbuf[g];
-                const double *sc = ssub + kg * 4;
-                const double SCt = SC + sc[0], SICt = SIC + sc[1], SCCt = SCC + (2. * h + sc[2]);
+                const double SCt = SC + sc0, SICt = SIC + sc1, SCCt = SCC + (2. * h + sc2);
                 // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
-                double S = a.SII, num = SICt, den = SCCt;
-                if (a.find_bg) {
-                    const double numc = SICt - SIoSw * SCt, denc = SCCt - SCt * invSw * SCt;
-                    const bool neg_b = a.pos_bg && (a.SI * denc - numc * SCt < 0.);
-                    if (!neg_b) { S = Scen; num = numc; den = denc; }
+                double S = cSII, num = SICt, den = SCCt;
+                if (find_bg) {
+                    const double numc = SICt - cSIoSw * SCt, denc = SCCt - SCt * cinvSw * SCt;
+                    const bool neg_b = pos_bg && (cSI * denc - numc * SCt < 0.);
+                    if (!neg_b) { S = cScen; num = numc; den = denc; }
                 }
                 const bool acc_g = (g < gcount) && (num * num > (S - X) * den);   // chi²_t < chi² (mcsas.py:379)
                 unsigned amask = (unsigned)(__ballot(acc_g) & 0xFFull);
-                if (a.pad0 & 32) amask = 0u;                        // diagnostic: never accept
-                const unsigned ovm = (unsigned)(__ballot((g < gcount) && osub[kg]) & 0xFFull);
+                if (never_accept) amask = 0u;                       // diagnostic: never accept
+                const unsigned ovm = (unsigned)(__ballot((g < gcount) && ovg) & 0xFFull);
                 int k_next, acc_row = -1;
                 if (amask == 0u) {
                     if (ovm) overflow = 1;
@@ -398,8 +436,11 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     if (ovm & ((2u << ga) - 1u)) overflow = 1;
                     acc_row = k + ga;
                     SC = readlane_f64(SCt, ga); SIC = readlane_f64(SICt, ga); SCC = readlane_f64(SCCt, ga);
-                    cur = solve_fit(a, SC, SCC, SIC);
-                    X = cur.chi2 * nqd;
+                    // chi²·Q of the accepted state from the same three numbers the decision used (one
+                    // division); scale and background are only needed at the end of the attempt
+                    X = readlane_f64(S - num * num / den, ga);
+                    MCSAS_IN_VGPR(SC); MCSAS_IN_VGPR(SIC); MCSAS_IN_VGPR(SCC); MCSAS_IN_VGPR(X);
+                    cur.chi2 = X / cnq;
                     const int fresh = lstage[acc_row], freed = lslot[acc_row];
                     if (lane == 0) {
                         lslot[acc_row] = fresh; lstage[acc_row] = freed;      // slot swap: rows are never copied
@@ -408,14 +449,23 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     ++num_acc_win; ++num_moves;
                     touched = true;
                     k_next = acc_row + 1; num_iter += ga + 1;
-                    if (!(cur.chi2 > a.conv_crit)) live = false;
+                    if (!(X > cCrit * cnq)) live = false;
                 }
                 if (lane == 0) { ctl[0] = k_next; ctl[1] = acc_row; ctl[2] = live ? 1 : 0; }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MCSAS_STAMP(s7);
             __builtin_amdgcn_s_barrier();                                  // B2: decision published
+            MCSAS_STAMP(s8);
             const int k_next = ctl[0], acc_row = ctl[1];
             live = ctl[2] != 0;
+            if (wave == 0) {
+                const int m_keep = (k + ((wave - (k & 7) + 8) & 7)) >> 3;
+                while (m_cur < m_keep) {
+                    ++m_cur;
+                    if (m_issue < my_rows && !dbg_noload) { issue_row(m_issue); ++m_issue; }
+                }
+            }
             if (acc_row >= 0) {
                 if ((acc_row & 7) == wave) {
                     // the owner of the accepted row applies it: ft += d, w ft refreshed (mcsas.py:381-382)
@@ -439,7 +489,15 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 for (int j = 0; j < QPL; ++j) wftr[j] = lwft[lane + WAVE * j];
             }
             k = k_next;
+#ifdef MCSAS_STAMPS
+            MCSAS_STAMP(s9);
+            if (mine) { ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3; ph[4] += s5 - s4; ph[10] += 1; }
+            ph[5] += s6 - s5; ph[6] += s7 - s6; ph[7] += s8 - s7; ph[8] += s9 - s8; ph[9] += s9 - s0; ph[11] += 1;
+#endif
         }
+#ifdef MCSAS_STAMPS
+        if (wave == 0 && lane == 0) for (int i = 0; i < 12; ++i) ch.dbg[i] += ph[i];
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // no DMA may outlive the ring
         if (wave == 0 && lane == 0) lacc[Kb] = num_acc_win;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -536,6 +594,9 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 o.num_iter = num_iter; o.num_moves = num_moves; o.draws = (int64_t)draw_pos;
                 o.total_steps = total_steps;
                 o.attempts = attempts; o.converged = converged; o.stream_overflow = ch.overflow | overflow; o.stopped = stopped;
+#ifdef MCSAS_STAMPS
+                for (int i = 0; i < 16; ++i) o.dbg[i] = ch.dbg[i];
+#endif
                 a.out[rep] = o;
                 __hip_atomic_fetch_add(pa.n_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }

@@ -509,6 +509,17 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
     int64_t steps = 0; int ovf = 0;
     for (size_t r = 0; r < R; ++r) { steps += ho[r].total_steps; ovf |= ho[r].stream_overflow; }
     pl->last_steps = steps;
+#ifdef MCSAS_STAMPS
+    {
+        static const char *names[12] = {"retire+issue", "vmcnt wait", "lds+fma", "wave_sum", "hbuf write", "B1 wait",
+                                        "decide(+idle)", "B2 wait", "ctl read+accept", "group total", "groups(mine)", "groups"};
+        for (size_t r = 0; r < R && r < 2; ++r) {
+            fprintf(stderr, "[mcsas stamps] rep %zu (wave 0 cycles):", r);
+            for (int i = 0; i < 12; ++i) fprintf(stderr, " %s=%lld", names[i], (long long)ho[r].dbg[i]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     if (res) {
         if (res->contribs) {
             std::vector<double> hr(R * N * P);
