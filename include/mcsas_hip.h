@@ -33,7 +33,11 @@ enum {
     MCSAS_MODEL_CYL_ISO = 1,     /* models/cylindersisotropic.py:17-101 (radius, useAspect, length, aspect, intDiv, sld) */
     MCSAS_MODEL_ELL_CS = 2,      /* models/ellipsoidalcoreshell.py:14-97 (a, b, t, eta_c, eta_s, eta_sol, intDiv) */
     MCSAS_MODEL_KHOLODENKO = 3,  /* models/kholodenko.py:51-94         (radius, lenKuhn, lenContour) */
-    MCSAS_MODEL_COUNT = 4
+    MCSAS_MODEL_ELL_ISO = 4,     /* models/ellipsoidsisotropic.py:18-84 (a, useAspect, c, aspect, intDiv, sld) */
+    MCSAS_MODEL_SPH_CS = 5,      /* models/sphericalcoreshell.py:14-77 (radius, t, eta_c, eta_s, eta_sol) */
+    MCSAS_MODEL_GAUSS_CHAIN = 6, /* models/gaussianchain.py:14-66      (rg, bp, etas, k) */
+    MCSAS_MODEL_LMA_SPHERE = 7,  /* models/lmadensesphere.py:14-106    (radius, volFrac, mf, sld) */
+    MCSAS_MODEL_COUNT = 8
 };
 
 /* gen_kind: NumberGenerator subclass of an active parameter (bases/algorithm/numbergenerator.py) */

@@ -10,7 +10,8 @@ from .engine import (ModelSetup, Settings, analyse, model_calc, bgfit, observabi
 from .parameter import (Parameter, FitParameter, RandomUniform, RandomExponential,               # noqa: F401
                         RandomExponential1, RandomExponential2, RandomExponential3, Histogram)
 from .scatteringmodels import (ScatteringModel, SASModel, SASModelData, Sphere,                   # noqa: F401
-                               CylindersIsotropic, EllipsoidalCoreShell, Kholodenko, setup_from_model)
+                               CylindersIsotropic, EllipsoidalCoreShell, Kholodenko, EllipsoidsIsotropic,
+                               SphericalCoreShell, GaussianChain, LMADenseSphere, setup_from_model)
 from .dataobj import SASData                                                                      # noqa: F401
 from .mcsas import McSAS                                                                          # noqa: F401
 

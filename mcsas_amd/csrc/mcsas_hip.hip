@@ -117,6 +117,7 @@ static int model_int_div(const mcsas_problem *p) {
     switch (p->model_id) {
         case MCSAS_MODEL_CYL_ISO: return (int)p->params[4];
         case MCSAS_MODEL_ELL_CS: return (int)p->params[6];
+        case MCSAS_MODEL_ELL_ISO: return (int)p->params[4];
         default: return 1;
     }
 }
@@ -136,15 +137,19 @@ static int fill_model_args(const mcsas_problem *p, ModelArgs *m) {
     m->int_div = model_int_div(p);
     m->qmax = 0.;
     if (p->q) for (int i = 0; i < p->nq; ++i) m->qmax = std::max(m->qmax, std::fabs(p->q[i]));
-    if ((p->model_id == MCSAS_MODEL_CYL_ISO || p->model_id == MCSAS_MODEL_ELL_CS) && (m->int_div < 2 || m->int_div > 4096))
+    if ((p->model_id == MCSAS_MODEL_CYL_ISO || p->model_id == MCSAS_MODEL_ELL_CS || p->model_id == MCSAS_MODEL_ELL_ISO) &&
+        (m->int_div < 2 || m->int_div > 4096))
         return fail(MCSAS_EINVAL, "intDiv %d unsupported (2..4096)", m->int_div);
     return MCSAS_OK;
 }
 
 static int table_doubles_host(int model_id, int K) {
-    if (model_id == MCSAS_MODEL_SPHERE) return 0;
-    if (model_id == MCSAS_MODEL_KHOLODENKO) return 32;
-    return 2 * K;
+    switch (model_id) {
+        case MCSAS_MODEL_CYL_ISO: case MCSAS_MODEL_ELL_CS: return 2 * K;
+        case MCSAS_MODEL_ELL_ISO: return 3 * K;
+        case MCSAS_MODEL_KHOLODENKO: return 32;
+        default: return 0;
+    }
 }
 
 static int select_device(int device) {
@@ -185,38 +190,34 @@ struct mcsas_plan {
 };
 
 // kernel lookups, one translation unit per model (kern_wave.hip / kern_wg.hip)
-void *mcsas_wave_kernel_m0(int, bool); void *mcsas_wave_kernel_m1(int, bool);
-void *mcsas_wave_kernel_m2(int, bool); void *mcsas_wave_kernel_m3(int, bool);
-void *mcsas_wg_kernel_m0(int); void *mcsas_wg_kernel_m1(int); void *mcsas_wg_kernel_m2(int); void *mcsas_wg_kernel_m3(int);
-void *mcsas_pipe_tick_kernel_m0(int); void *mcsas_pipe_tick_kernel_m1(int);
-void *mcsas_pipe_tick_kernel_m2(int); void *mcsas_pipe_tick_kernel_m3(int);
+#define MCSAS_FOR_MODELS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define DECL_K(m) void *mcsas_wave_kernel_m##m(int, bool); void *mcsas_wg_kernel_m##m(int); void *mcsas_pipe_tick_kernel_m##m(int);
+MCSAS_FOR_MODELS(DECL_K)
+#undef DECL_K
 void *mcsas_pipe_reset_kernel();
 
 static void *pipe_tick_kernel_for(int model, int qpl) {
     switch (model) {
-        case MCSAS_MODEL_SPHERE: return mcsas_pipe_tick_kernel_m0(qpl);
-        case MCSAS_MODEL_CYL_ISO: return mcsas_pipe_tick_kernel_m1(qpl);
-        case MCSAS_MODEL_ELL_CS: return mcsas_pipe_tick_kernel_m2(qpl);
-        case MCSAS_MODEL_KHOLODENKO: return mcsas_pipe_tick_kernel_m3(qpl);
+#define CASE_K(m) case m: return mcsas_pipe_tick_kernel_m##m(qpl);
+        MCSAS_FOR_MODELS(CASE_K)
+#undef CASE_K
         default: return nullptr;
     }
 }
 
 static void *wave_kernel_for(int model, int qpl, bool cache) {
     switch (model) {
-        case MCSAS_MODEL_SPHERE: return mcsas_wave_kernel_m0(qpl, cache);
-        case MCSAS_MODEL_CYL_ISO: return mcsas_wave_kernel_m1(qpl, cache);
-        case MCSAS_MODEL_ELL_CS: return mcsas_wave_kernel_m2(qpl, cache);
-        case MCSAS_MODEL_KHOLODENKO: return mcsas_wave_kernel_m3(qpl, cache);
+#define CASE_K(m) case m: return mcsas_wave_kernel_m##m(qpl, cache);
+        MCSAS_FOR_MODELS(CASE_K)
+#undef CASE_K
         default: return nullptr;
     }
 }
 static void *wg_kernel_for(int model, int qpl) {
     switch (model) {
-        case MCSAS_MODEL_SPHERE: return mcsas_wg_kernel_m0(qpl);
-        case MCSAS_MODEL_CYL_ISO: return mcsas_wg_kernel_m1(qpl);
-        case MCSAS_MODEL_ELL_CS: return mcsas_wg_kernel_m2(qpl);
-        case MCSAS_MODEL_KHOLODENKO: return mcsas_wg_kernel_m3(qpl);
+#define CASE_K(m) case m: return mcsas_wg_kernel_m##m(qpl);
+        MCSAS_FOR_MODELS(CASE_K)
+#undef CASE_K
         default: return nullptr;
     }
 }
@@ -605,14 +606,9 @@ extern "C" int mcsas_hip_model_calc(const mcsas_problem *p, const double *pset, 
     HIPCHK(hipMemcpy(dp.p, pset, sizeof(double) * n * P, hipMemcpyHostToDevice));
     size_t lds = sizeof(double) * table_doubles_host(p->model_id, m.int_div);
     switch (p->model_id) {
-        case MCSAS_MODEL_SPHERE:
-            model_rows_kernel<MCSAS_MODEL_SPHERE><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
-        case MCSAS_MODEL_CYL_ISO:
-            model_rows_kernel<MCSAS_MODEL_CYL_ISO><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
-        case MCSAS_MODEL_ELL_CS:
-            model_rows_kernel<MCSAS_MODEL_ELL_CS><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
-        case MCSAS_MODEL_KHOLODENKO:
-            model_rows_kernel<MCSAS_MODEL_KHOLODENKO><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
+#define CASE_K(mm) case mm: model_rows_kernel<mm><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
+        MCSAS_FOR_MODELS(CASE_K)
+#undef CASE_K
         default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
     }
     HIPCHK(hipGetLastError());
@@ -663,14 +659,9 @@ extern "C" int mcsas_hip_observability(const mcsas_problem *p, const double *con
     size_t lds = sizeof(double) * table_doubles_host(p->model_id, m.int_div);
     dim3 grid((unsigned)N, (unsigned)R);
     switch (p->model_id) {
-        case MCSAS_MODEL_SPHERE:
-            observability_kernel<MCSAS_MODEL_SPHERE><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
-        case MCSAS_MODEL_CYL_ISO:
-            observability_kernel<MCSAS_MODEL_CYL_ISO><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
-        case MCSAS_MODEL_ELL_CS:
-            observability_kernel<MCSAS_MODEL_ELL_CS><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
-        case MCSAS_MODEL_KHOLODENKO:
-            observability_kernel<MCSAS_MODEL_KHOLODENKO><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
+#define CASE_K(mm) case mm: observability_kernel<mm><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
+        MCSAS_FOR_MODELS(CASE_K)
+#undef CASE_K
         default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
     }
     HIPCHK(hipGetLastError());

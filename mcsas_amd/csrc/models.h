@@ -297,6 +297,162 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
     }
 };
 
+// ---------------------------------------------------------------------------------- Isotropic ellipsoids
+// models/ellipsoidsisotropic.py:51-84.  table: sin^2(alpha_k), cos^2(alpha_k), sin(alpha_k),
+// alpha = linspace(0, pi/2, K)
+template <> struct Contrib<MCSAS_MODEL_ELL_ISO> {
+    double ra2, rc2, v, w, s, invK;
+    int K;
+    static __device__ __forceinline__ int table_doubles(int K) { return 3 * K; }
+    static __device__ __forceinline__ void fill_table(const ModelArgs &a, double *tab, int tid, int nt) {
+        const int K = a.int_div;
+        const double step = (PI / 2.) / (double)(K - 1);
+        for (int k = tid; k < K; k += nt) {
+            const double al = (k == K - 1) ? PI / 2. : (double)k * step;   // numpy.linspace(0, pi/2, K)
+            const double sn = sin(al), cs = cos(al);
+            tab[k] = sn * sn; tab[K + k] = cs * cs; tab[2 * K + k] = sn;
+        }
+    }
+    __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
+        double p[MCSAS_MAX_PARAMS];
+        full_params(a, row, p);
+        const double ra = p[0];
+        const double rc = (p[1] != 0.0) ? ra * p[3] : p[2];          // :63-66
+        ra2 = ra * ra; rc2 = rc * rc;
+        const double vol = 4. / 3. * PI * (ra * ra) * rc;            // :80
+        v = vol * (p[5] * p[5]);                                     // :83-84
+        s = 0.;
+        w = pow(vol, 2. * a.comp_exp);
+        K = a.int_div; invK = 1.0 / (double)K;
+    }
+    __device__ __forceinline__ Contrib bcast(int lane) const {
+        Contrib o; o.ra2 = readlane_f64(ra2, lane); o.rc2 = readlane_f64(rc2, lane);
+        o.w = readlane_f64(w, lane); o.v = 0.; o.s = 0.; o.invK = invK; o.K = K;
+        return o;
+    }
+    __device__ __forceinline__ double intensity(double q, const double *tab) const {
+        double acc = 0.;
+        for (int k = 0; k < K; ++k) {
+            const double x = q * sqrt(ra2 * tab[k] + rc2 * tab[K + k]);   // rPlugin (:56-58)
+            double sn, cs;
+            sincos_fast(x, &sn, &cs);
+            const double f = div_fast(3. * (sn - x * cs), x * x * x);
+            acc += (f * f) * tab[2 * K + k];
+        }
+        const double ff = sqrt(acc * invK);                           // :73
+        return ff * ff * w;
+    }
+};
+
+// ---------------------------------------------------------------------------------- Core-shell sphere
+// models/sphericalcoreshell.py:50-77
+template <> struct Contrib<MCSAS_MODEL_SPH_CS> {
+    double r, rt, ds, dc, vr, v, w, s;
+    static __device__ __forceinline__ int table_doubles(int) { return 0; }
+    static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
+    __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
+        double p[MCSAS_MAX_PARAMS];
+        full_params(a, row, p);
+        r = p[0]; rt = p[0] + p[1];
+        const double vc = 4. / 3 * PI * (r * r * r);
+        const double vt = 4. / 3 * PI * (rt * rt * rt);
+        vr = vc / vt;
+        ds = p[3] - p[4];                 // eta_s - eta_sol
+        dc = p[3] - p[2];                 // eta_s - eta_c
+        v = vt; s = 0.;                   // volume() == absVolume()
+        w = pow(vt, 2. * a.comp_exp);
+    }
+    __device__ __forceinline__ Contrib bcast(int lane) const {
+        Contrib o; o.r = readlane_f64(r, lane); o.rt = readlane_f64(rt, lane); o.ds = readlane_f64(ds, lane);
+        o.dc = readlane_f64(dc, lane); o.vr = readlane_f64(vr, lane); o.w = readlane_f64(w, lane); o.v = 0.; o.s = 0.;
+        return o;
+    }
+    __device__ __forceinline__ double intensity(double q, const double *) const {
+        double sn, cs;
+        const double xs = q * rt;
+        sincos_fast(xs, &sn, &cs);
+        const double ks = div_fast(ds * 3. * (sn - xs * cs), xs * xs * xs);
+        const double xc = q * r;
+        sincos_fast(xc, &sn, &cs);
+        const double kc = div_fast(dc * 3. * (sn - xc * cs), xc * xc * xc);
+        const double f = ks - vr * kc;
+        return f * f * w;
+    }
+};
+
+// ---------------------------------------------------------------------------------- Gaussian chain
+// models/gaussianchain.py:54-66
+template <> struct Contrib<MCSAS_MODEL_GAUSS_CHAIN> {
+    double rg, beta, v, w, s;
+    static __device__ __forceinline__ int table_doubles(int) { return 0; }
+    static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
+    __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
+        double p[MCSAS_MAX_PARAMS];
+        full_params(a, row, p);
+        rg = p[0];
+        const double vol = p[3] * (rg * rg);          // k * rg^2 (:63-65)
+        beta = p[1] - vol * p[2];                     // bp - (k rg^2) etas (:56)
+        v = vol; s = 0.;
+        w = pow(vol, 2. * a.comp_exp);
+    }
+    __device__ __forceinline__ Contrib bcast(int lane) const {
+        Contrib o; o.rg = readlane_f64(rg, lane); o.beta = readlane_f64(beta, lane); o.w = readlane_f64(w, lane);
+        o.v = 0.; o.s = 0.;
+        return o;
+    }
+    __device__ __forceinline__ double intensity(double q, const double *) const {
+        const double x = q * rg, u = x * x;
+        double f = sqrt(2.) * sqrt(expm1(-u) + u) / u;
+        f *= beta;
+        if (q <= 0.0) f = beta;
+        return f * f * w;
+    }
+};
+
+// ---------------------------------------------------------------------------------- LMA dense spheres
+// models/lmadensesphere.py:58-106: sphere form factor times a Percus-Yevick structure factor
+template <> struct Contrib<MCSAS_MODEL_LMA_SPHERE> {
+    double r, rh, mu, al, be, ga, v, w, s;
+    static __device__ __forceinline__ int table_doubles(int) { return 0; }
+    static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
+    __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
+        double p[MCSAS_MAX_PARAMS];
+        full_params(a, row, p);
+        r = p[0]; mu = p[1];
+        double mf = p[2];
+        if (mf == -1.) mf = pow(0.634 / mu, 1. / 3);                  // :72-73
+        rh = mf * r;
+        const double om = (1. - mu) * (1. - mu) * (1. - mu) * (1. - mu);
+        al = (1. + 2. * mu) * (1. + 2. * mu) / om;                    // :76
+        be = -6. * mu * (1. + mu / 2.) * (1. + mu / 2.) / om;         // :77
+        ga = mu * al / 2.;                                            // :78
+        const double vol = (PI * 4. / 3.) * (r * r * r);
+        v = vol * (p[3] * p[3]); s = 0.;
+        w = pow(vol, 2. * a.comp_exp);
+    }
+    __device__ __forceinline__ Contrib bcast(int lane) const {
+        Contrib o; o.r = readlane_f64(r, lane); o.rh = readlane_f64(rh, lane); o.mu = readlane_f64(mu, lane);
+        o.al = readlane_f64(al, lane); o.be = readlane_f64(be, lane); o.ga = readlane_f64(ga, lane);
+        o.w = readlane_f64(w, lane); o.v = 0.; o.s = 0.;
+        return o;
+    }
+    __device__ __forceinline__ double intensity(double q, const double *) const {
+        double sn, cs;
+        const double x = q * r;
+        sincos_fast(x, &sn, &cs);
+        const double f = div_fast(3. * (sn - x * cs), x * x * x);
+        const double A = 2. * q * rh;                                 // :90
+        sincos_fast(A, &sn, &cs);
+        const double A2 = A * A, A3 = A2 * A, A4 = A2 * A2, A5 = A4 * A;
+        const double G = al * (sn - A * cs) / A2
+                       + be * (2. * A * sn + (2. - A2) * cs - 2.) / A3
+                       + ga * (-1. * A4 * cs + 4. * ((3. * A2 - 6.) * cs + (A3 - 6. * A) * sn + 6.)) / A5;   // :79-85
+        const double S = 1. / (1. + 24. * mu * G / A);                // :92
+        const double ff = sqrt(f * f * S);                            // :99
+        return ff * ff * w;
+    }
+};
+
 // ---------------------------------------------------------------------------------- row evaluation
 // out[j] = I(q[lane + 64 j]) for one contribution; the wave-uniform fast/slow choice is made once
 // per row so the QPL evaluations stay in one basic block and interleave.

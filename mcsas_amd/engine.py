@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import MAX_ACTIVE, MAX_PARAMS, Problem, Result, as_dp, check, f64
 
 MODEL_SPHERE, MODEL_CYL_ISO, MODEL_ELL_CS, MODEL_KHOLODENKO = 0, 1, 2, 3
+MODEL_ELL_ISO, MODEL_SPH_CS, MODEL_GAUSS_CHAIN, MODEL_LMA_SPHERE = 4, 5, 6, 7
 EXEC_AUTO, EXEC_WAVE, EXEC_WORKGROUP, EXEC_PIPELINE = 0, 1, 2, 3
 GEN_UNIFORM, GEN_EXP1, GEN_EXP2, GEN_EXP3 = 0, 1, 2, 3
 INT64_MAX = (1 << 63) - 1

@@ -176,9 +176,88 @@ class Kholodenko(SASModel):
         self.lenContour.setActive(True)
 
 
+class EllipsoidsIsotropic(SASModel):
+    """models/ellipsoidsisotropic.py:18-86."""
+    shortName = "Isotropic Ellipsoids"
+    model_id = engine.MODEL_ELL_ISO
+    parameters = (
+        _fp("a", 1. * NM, displayName="Radius of semi-axes a, b", generator=RandomExponential,
+            valueRange=(0.1 * NM, 1e10 * NM), activeRange=(0.1 * NM, 1e3 * NM)),
+        _p("useAspect", True, displayName="Use aspect ratio (checked) or length to define c-axis"),
+        _fp("c", 10. * NM, displayName="Radius of semi-axes c", generator=RandomExponential,
+            valueRange=(0.1 * NM, 1e10 * NM), activeRange=(1. * NM, 1e4 * NM)),
+        _fp("aspect", 10.0, displayName="aspect ratio of semi-axes c to a, b", generator=RandomExponential,
+            valueRange=(1e-3, 1e3)),
+        _p("intDiv", 100, displayName="Orientation Integration Divisions", valueRange=(0, 1e4)),
+        _p("sld", 1e-6 * SLD_A2, displayName="Scattering length density difference", valueRange=(0, 1e-2 * SLD_A2)),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.a.setActive(True)
+
+
+class SphericalCoreShell(SASModel):
+    """models/sphericalcoreshell.py:14-79."""
+    shortName = "Core-Shell Sphere"
+    model_id = engine.MODEL_SPH_CS
+    parameters = (
+        _fp("radius", 1. * NM, displayName="Core Radius", generator=RandomExponential,
+            valueRange=(0., np.inf), activeRange=(0.1 * NM, 1e3 * NM)),
+        _fp("t", 1. * NM, displayName="Thickness of Shell", generator=RandomExponential,
+            valueRange=(0., np.inf), activeRange=(0.1 * NM, 1e3 * NM)),
+        _p("eta_c", 3.16e-6 * SLD_A2, displayName="Core SLD", valueRange=(0, np.inf)),
+        _p("eta_s", 2.53e-6 * SLD_A2, displayName="Shell SLD", valueRange=(0, np.inf)),
+        _p("eta_sol", 0., displayName="Solvent SLD", valueRange=(0, np.inf)),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.radius.setActive(True)
+
+
+class GaussianChain(SASModel):
+    """models/gaussianchain.py:14-76."""
+    shortName = "Gaussian Chain"
+    model_id = engine.MODEL_GAUSS_CHAIN
+    parameters = (
+        _fp("rg", 1. * NM, displayName="radius of gyration, Rg", generator=RandomExponential,
+            valueRange=(0., np.inf), activeRange=(1.0 * NM, 1e2 * NM)),
+        _fp("bp", 100. * NM, displayName="scattering length of the polymer", generator=RandomUniform,
+            valueRange=(0., np.inf), activeRange=(0.1 * NM, 1e3 * NM)),
+        _fp("etas", 1e-6 * SLD_A2, displayName="scattering length density of the solvent", generator=RandomUniform,
+            valueRange=(0., np.inf), activeRange=(0.1 * SLD_A2, 10. * SLD_A2)),
+        _fp("k", 1.0, displayName="volumetric scaling factor of Rg", generator=RandomUniform,
+            valueRange=(0., np.inf), activeRange=(0.1, 10.)),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.rg.setActive(True)
+
+
+class LMADenseSphere(SASModel):
+    """models/lmadensesphere.py:14-108."""
+    shortName = "LMADenseSphere"
+    model_id = engine.MODEL_LMA_SPHERE
+    canSmear = True
+    parameters = (
+        _fp("radius", 1. * NM, displayName="Sphere radius", valueRange=(0., np.inf), generator=RandomUniform),
+        _fp("volFrac", 0.10, displayName="Volume fraction of spheres", valueRange=(0.001e-2, 1.0), generator=RandomUniform),
+        _p("mf", -1., displayName="standoff multiplier (-1 = auto)", valueRange=(-1., 1.e6)),
+        _p("sld", 1e-6 * SLD_A2, displayName="Scattering length density difference", valueRange=(0., np.inf)),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.radius.setActive(True)
+
+
 # reference class name -> kernel id (FindModels walks models/*.py, utils/findmodels.py:120-186)
 MODEL_IDS = {"Sphere": engine.MODEL_SPHERE, "CylindersIsotropic": engine.MODEL_CYL_ISO,
-             "EllipsoidalCoreShell": engine.MODEL_ELL_CS, "Kholodenko": engine.MODEL_KHOLODENKO}
+             "EllipsoidalCoreShell": engine.MODEL_ELL_CS, "Kholodenko": engine.MODEL_KHOLODENKO,
+             "EllipsoidsIsotropic": engine.MODEL_ELL_ISO, "SphericalCoreShell": engine.MODEL_SPH_CS,
+             "GaussianChain": engine.MODEL_GAUSS_CHAIN, "LMADenseSphere": engine.MODEL_LMA_SPHERE}
 
 
 def setup_from_model(model, data=None) -> engine.ModelSetup:

@@ -63,6 +63,10 @@ from mcsas.models.sphere import Sphere                        # noqa: E402
 from mcsas.models.cylindersisotropic import CylindersIsotropic    # noqa: E402
 from mcsas.models.ellipsoidalcoreshell import EllipsoidalCoreShell  # noqa: E402
 from mcsas.models.kholodenko import Kholodenko                # noqa: E402
+from mcsas.models.ellipsoidsisotropic import EllipsoidsIsotropic   # noqa: E402
+from mcsas.models.sphericalcoreshell import SphericalCoreShell      # noqa: E402
+from mcsas.models.gaussianchain import GaussianChain          # noqa: E402
+from mcsas.models.lmadensesphere import LMADenseSphere        # noqa: E402
 from mcsas.utils.parameter import Histogram                   # noqa: E402
 from mcsas.bases.algorithm.numbergenerator import (RandomUniform, RandomExponential,   # noqa: E402
                                    RandomExponential2, RandomExponential3)
@@ -180,6 +184,33 @@ def model_cases():
         return Kholodenko()
     cases.append(("kholodenko", kho, ["radius", "lenKuhn", "lenContour"],
                   [[1e-9, 1e-8, 1e-6], [3e-9, 3e-8, 2.5e-7], [5e-9, 5e-8, 1e-7], [1.2e-9, 1.0e-8, 9.9e-7]]))
+    def elliso():
+        m = EllipsoidsIsotropic()
+        m.a.setActive(True); m.aspect.setActive(True)
+        return m
+    cases.append(("elliso", elliso, ["a", "aspect"],
+                  [[1e-9, 10.0], [5e-9, 0.3], [2.5e-8, 2.0], [1e-7, 1.0]]))
+
+    def sphcs():
+        m = SphericalCoreShell()
+        m.radius.setActive(True); m.t.setActive(True)
+        return m
+    cases.append(("sphcs", sphcs, ["radius", "t"],
+                  [[1e-9, 1e-9], [1e-8, 5e-9], [1e-7, 2e-10], [3e-9, 3e-8]]))
+
+    def gchain():
+        m = GaussianChain()
+        m.rg.setActive(True); m.bp.setActive(True)
+        return m
+    cases.append(("gausschain", gchain, ["rg", "bp"],
+                  [[1e-9, 1e-7], [1e-8, 5e-8], [6e-8, 3e-7], [2.5e-9, 1e-9]]))
+
+    def lma():
+        m = LMADenseSphere()
+        m.radius.setActive(True); m.volFrac.setActive(True)
+        return m
+    cases.append(("lmasphere", lma, ["radius", "volFrac"],
+                  [[1e-9, 0.1], [1e-8, 0.3], [8e-8, 0.02], [3e-9, 0.45]]))
     return cases
 
 
@@ -391,6 +422,40 @@ def gen_trajectories():
                  comp_exp=0.6666666, max_iter=250, conv_crit=1e-9, eta_c=me.eta_c(), eta_s=me.eta_s(),
                  eta_sol=me.eta_sol(), int_div=100)
     save_traj("g4_ellcs_q40.npz", dv5, spec5, run_mcfit(algo, 40, 1005))
+
+    # T7..T10: the four plugin models outside the BASELINE configs, short runs
+    q_nm = np.logspace(np.log10(0.02), np.log10(2.0), 40)
+    dtmp = sasdata(q_nm, np.ones(40), 0.01 * np.ones(40))
+
+    def short_traj(tag, model, names, lo, hi, gen, truth, fname, extra_spec):
+        for n, l, h in zip(names, lo, hi):
+            getattr(model, n).setActive(True)
+            getattr(model, n).setActiveRange((l, h))
+        It = np.array(model.calc(dtmp, truth, 0.6666666).cumInt)
+        It = It / It.max() * 1e3
+        dd = sasdata(q_nm, It * (1 + 0.01 * rs.normal(size=40)), 0.01 * It)
+        algo = new_algo(numContribs=40, numReps=1, maxIterations=250, convergenceCriterion=1e-9)
+        algo.model = model; algo.data = dd
+        spec = dict(model=tag, n_contrib=40, lo=lo, hi=hi, gen=gen, comp_exp=0.6666666, max_iter=250, conv_crit=1e-9)
+        spec.update(extra_spec)
+        save_traj(fname, data_vectors(dd), spec, run_mcfit(algo, 40, 1100 + len(fname)))
+
+    mei = EllipsoidsIsotropic()
+    short_traj("elliso", mei, ["a", "aspect"], [1e-9, 0.2], [5e-8, 20.0], [1, 1],
+               np.stack([rs.uniform(3e-9, 2e-8, 30), rs.uniform(0.5, 5, 30)], axis=1), "g4_elliso_q40.npz",
+               dict(sld=mei.sld(), int_div=100))
+    msc = SphericalCoreShell()
+    short_traj("sphcs", msc, ["radius", "t"], [1e-9, 2e-10], [5e-8, 1e-8], [1, 1],
+               np.stack([rs.uniform(3e-9, 2e-8, 30), rs.uniform(5e-10, 5e-9, 30)], axis=1), "g4_sphcs_q40.npz",
+               dict(eta_c=msc.eta_c(), eta_s=msc.eta_s(), eta_sol=msc.eta_sol()))
+    mgc = GaussianChain()
+    short_traj("gausschain", mgc, ["rg", "bp"], [1e-9, 1e-9], [1e-7, 1e-6], [1, 0],
+               np.stack([rs.uniform(3e-9, 4e-8, 30), rs.uniform(1e-8, 5e-7, 30)], axis=1), "g4_gausschain_q40.npz",
+               dict(etas=mgc.etas(), k=mgc.k()))
+    mlm = LMADenseSphere()
+    short_traj("lmasphere", mlm, ["radius", "volFrac"], [1e-9, 0.01], [5e-8, 0.4], [0, 0],
+               np.stack([rs.uniform(3e-9, 2e-8, 30), rs.uniform(0.05, 0.3, 30)], axis=1), "g4_lmasphere_q40.npz",
+               dict(sld=mlm.sld(), mf=mlm.mf()))
 
     # T6: Kholodenko worm (3 active), tiny (QUADPACK is slow)
     q_nm = np.logspace(np.log10(0.02), np.log10(2.0), 24)

@@ -25,8 +25,9 @@ import numpy as np
 _trapz = getattr(np, "trapezoid", None) or np.trapz
 
 # ----------------------------------------------------------------------------- model registry
-SPHERE, CYL_ISO, ELL_CS, KHOLODENKO = 0, 1, 2, 3
-MODEL_IDS = {"sphere": SPHERE, "cyl": CYL_ISO, "ellcs": ELL_CS, "kholodenko": KHOLODENKO}
+SPHERE, CYL_ISO, ELL_CS, KHOLODENKO, ELL_ISO, SPH_CS, GAUSS_CHAIN, LMA_SPHERE = 0, 1, 2, 3, 4, 5, 6, 7
+MODEL_IDS = {"sphere": SPHERE, "cyl": CYL_ISO, "ellcs": ELL_CS, "kholodenko": KHOLODENKO,
+             "elliso": ELL_ISO, "sphcs": SPH_CS, "gausschain": GAUSS_CHAIN, "lmasphere": LMA_SPHERE}
 
 GEN_UNIFORM, GEN_EXP1, GEN_EXP2, GEN_EXP3 = 0, 1, 2, 3
 
@@ -36,12 +37,20 @@ PARAM_NAMES = {
     CYL_ISO: ("radius", "useAspect", "length", "aspect", "intDiv", "sld"),  # cylindersisotropic.py:21-43
     ELL_CS: ("a", "b", "t", "eta_c", "eta_s", "eta_sol", "intDiv"),    # ellipsoidalcoreshell.py:19-52
     KHOLODENKO: ("radius", "lenKuhn", "lenContour"),                   # kholodenko.py:57-73
+    ELL_ISO: ("a", "useAspect", "c", "aspect", "intDiv", "sld"),       # ellipsoidsisotropic.py:24-46
+    SPH_CS: ("radius", "t", "eta_c", "eta_s", "eta_sol"),              # sphericalcoreshell.py:22-43
+    GAUSS_CHAIN: ("rg", "bp", "etas", "k"),                            # gaussianchain.py:27-48
+    LMA_SPHERE: ("radius", "volFrac", "mf", "sld"),                    # lmadensesphere.py:26-55
 }
 PARAM_DEFAULTS = {
     SPHERE: (10e-9, 1e-6 * 1e20),
     CYL_ISO: (1e-9, 1.0, 10e-9, 10.0, 100.0, 1e-6 * 1e20),
     ELL_CS: (1e-9, 10e-9, 1e-9, 3.15e-6 * 1e20, 2.53e-6 * 1e20, 0.0, 100.0),
     KHOLODENKO: (1e-9, 1e-9, 2e-9),
+    ELL_ISO: (1e-9, 1.0, 10e-9, 10.0, 100.0, 1e-6 * 1e20),
+    SPH_CS: (1e-9, 1e-9, 3.16e-6 * 1e20, 2.53e-6 * 1e20, 0.0),
+    GAUSS_CHAIN: (1e-9, 100e-9, 1e-6 * 1e20, 1.0),
+    LMA_SPHERE: (1e-9, 0.10, -1.0, 1e-6 * 1e20),
 }
 # valueRange (clip range applied by Parameter.setValue, bases/algorithm/parameter.py:405-414,489-495)
 PARAM_VALUE_RANGE = {
@@ -49,12 +58,20 @@ PARAM_VALUE_RANGE = {
     CYL_ISO: ((0.1e-9, np.inf), (0.0, 1.0), (0.1e-9, 1e10 * 1e-9), (1e-3, 1e3), (1.0, 1e4), (0.0, np.inf)),
     ELL_CS: ((0.0, np.inf),) * 6 + ((0.0, 1e4),),
     KHOLODENKO: ((0.0, np.inf),) * 3,
+    ELL_ISO: ((0.1e-9, 1e10 * 1e-9), (0.0, 1.0), (0.1e-9, 1e10 * 1e-9), (1e-3, 1e3), (0.0, 1e4), (0.0, 1e-2 * 1e20)),
+    SPH_CS: ((0.0, np.inf),) * 5,
+    GAUSS_CHAIN: ((0.0, np.inf),) * 4,
+    LMA_SPHERE: ((0.0, np.inf), (0.001e-2, 1.0), (-1.0, 1e6), (0.0, np.inf)),
 }
 PARAM_DEFAULT_GEN = {
     SPHERE: {"radius": GEN_UNIFORM},
     CYL_ISO: {"radius": GEN_EXP1, "length": GEN_EXP1, "aspect": GEN_EXP1},
     ELL_CS: {"a": GEN_EXP1, "b": GEN_EXP1, "t": GEN_EXP1},
     KHOLODENKO: {"radius": GEN_EXP1, "lenKuhn": GEN_UNIFORM, "lenContour": GEN_UNIFORM},
+    ELL_ISO: {"a": GEN_EXP1, "c": GEN_EXP1, "aspect": GEN_EXP1},
+    SPH_CS: {"radius": GEN_EXP1, "t": GEN_EXP1},
+    GAUSS_CHAIN: {"rg": GEN_EXP1, "bp": GEN_UNIFORM, "etas": GEN_UNIFORM, "k": GEN_UNIFORM},
+    LMA_SPHERE: {"radius": GEN_UNIFORM, "volFrac": GEN_UNIFORM},
 }
 
 
@@ -160,6 +177,57 @@ def ff_kholodenko(q, radius, len_kuhn, len_contour):
     return out
 
 
+def ff_ellipsoids_isotropic(q, ra, rc, int_div):
+    """models/ellipsoidsisotropic.py:51-73."""
+    al = np.linspace(0., np.pi / 2., int(int_div))
+    qrp = np.outer(q, np.sqrt(ra**2 * np.sin(al)**2 + rc**2 * np.cos(al)**2))
+    fsplit = 3. * (np.sin(qrp) - qrp * np.cos(qrp)) / (qrp**3.)
+    return np.sqrt(np.mean(fsplit**2 * np.sin(al), axis=1))
+
+
+def ff_spherical_core_shell(q, r, t, eta_c, eta_s, eta_sol):
+    """models/sphericalcoreshell.py:50-69."""
+    def k(q, rr, d_eta):
+        qr = np.outer(q, rr)
+        return d_eta * 3 * (np.sin(qr) - qr * np.cos(qr)) / (qr)**3
+    vc = 4. / 3 * np.pi * r**3
+    vt = 4. / 3 * np.pi * (r + t)**3
+    v_ratio = vc / vt
+    ks = k(q, r + t, eta_s - eta_sol)
+    kc = k(q, r, eta_s - eta_c)
+    return (ks - v_ratio * kc).flatten()
+
+
+def ff_gaussian_chain(q, rg, bp, etas, k):
+    """models/gaussianchain.py:54-61."""
+    beta = bp - (k * rg**2) * etas
+    u = (q * rg)**2
+    result = np.sqrt(2.) * np.sqrt(np.expm1(-u) + u) / u
+    result *= beta
+    result[q <= 0.0] = beta
+    return result
+
+
+def ff_lma_dense_sphere(q, r, mu, mf):
+    """models/lmadensesphere.py:68-100."""
+    if mf == -1:
+        mf = (0.634 / mu)**(1. / 3)
+
+    def sfg(A, mu):
+        alpha = (1 + 2 * mu)**2 / (1 - mu)**4
+        beta = -6 * mu * (1 + mu / 2)**2 / (1 - mu)**4
+        gamma = mu * alpha / 2
+        return (alpha * (np.sin(A) - A * np.cos(A)) / A**2
+                + beta * (2 * A * np.sin(A) + (2 - A**2) * np.cos(A) - 2) / A**3
+                + gamma * (-1 * A**4 * np.cos(A) + 4 * ((3 * A**2 - 6) * np.cos(A)
+                                                       + (A**3 - 6 * A) * np.sin(A) + 6)) / A**5)
+    qr = q * r
+    result = 3. * (np.sin(qr) - qr * np.cos(qr)) / (qr**3.)
+    rhsq = 2. * q * (mf * r)
+    S = ((1. + 24. * mu * sfg(rhsq, mu) / rhsq))**(-1)
+    return np.sqrt(result**2 * S)
+
+
 def _clip_full(spec: ModelSpec, row):
     """Full parameter vector for one contribution: active columns set from `row`, each clipped
     into its valueRange as Parameter.setValue does (bases/algorithm/parameter.py:405-414)."""
@@ -200,6 +268,31 @@ def calc_intensity(spec: ModelSpec, q, row, comp_exp):
         v = vol
         s = 0
         ff = ff_kholodenko(q, r, lk, lc)
+    elif mid == ELL_ISO:
+        ra, use_aspect, c, aspect, int_div, sld = p
+        rc = ra * aspect if use_aspect else c                  # ellipsoidsisotropic.py:63-66
+        vol = 4. / 3. * np.pi * ra**2. * rc                    # :75-81
+        v = vol * sld**2
+        s = 0
+        ff = ff_ellipsoids_isotropic(q, ra, rc, int_div)
+    elif mid == SPH_CS:
+        r, t, eta_c, eta_s, eta_sol = p
+        vol = 4. / 3 * np.pi * (r + t)**3                      # sphericalcoreshell.py:71-73
+        v = vol
+        s = 0
+        ff = ff_spherical_core_shell(q, r, t, eta_c, eta_s, eta_sol)
+    elif mid == GAUSS_CHAIN:
+        rg, bp, etas, kk = p
+        vol = kk * rg**2                                       # gaussianchain.py:63-65
+        v = vol
+        s = 0
+        ff = ff_gaussian_chain(q, rg, bp, etas, kk)
+    elif mid == LMA_SPHERE:
+        r, mu, mf, sld = p
+        vol = (np.pi * 4. / 3.) * r**3                         # lmadensesphere.py:61-63
+        v = vol * sld**2
+        s = 0
+        ff = ff_lma_dense_sphere(q, r, mu, mf)
     else:
         raise ValueError("unknown model id %r" % mid)
     w = vol**(2 * comp_exp)                                    # sasmodel.py:37-44

@@ -21,6 +21,10 @@ CASES = {
                        fixed=dict(useAspect=False)),
     "ellcs": dict(cls=mcsas_amd.EllipsoidalCoreShell, omodel="ellcs", active=["a", "b", "t"]),
     "kholodenko": dict(cls=mcsas_amd.Kholodenko, omodel="kholodenko", active=["radius", "lenKuhn", "lenContour"]),
+    "elliso": dict(cls=mcsas_amd.EllipsoidsIsotropic, omodel="elliso", active=["a", "aspect"]),
+    "sphcs": dict(cls=mcsas_amd.SphericalCoreShell, omodel="sphcs", active=["radius", "t"]),
+    "gausschain": dict(cls=mcsas_amd.GaussianChain, omodel="gausschain", active=["rg", "bp"]),
+    "lmasphere": dict(cls=mcsas_amd.LMADenseSphere, omodel="lmasphere", active=["radius", "volFrac"]),
 }
 GEN_CLS = {0: mcsas_amd.RandomUniform, 1: mcsas_amd.RandomExponential, 2: mcsas_amd.RandomExponential2,
            3: mcsas_amd.RandomExponential3}
@@ -60,6 +64,14 @@ def traj_setup(name):
     if model == "ellcs":
         extra.update(eta_c=float(g["spec_eta_c"]), eta_s=float(g["spec_eta_s"]),
                      eta_sol=float(g["spec_eta_sol"]), intDiv=float(g["spec_int_div"]))
+    if model == "elliso":
+        extra.update(sld=float(g["spec_sld"]), intDiv=float(g["spec_int_div"]))
+    if model == "sphcs":
+        extra.update(eta_c=float(g["spec_eta_c"]), eta_s=float(g["spec_eta_s"]), eta_sol=float(g["spec_eta_sol"]))
+    if model == "gausschain":
+        extra.update(etas=float(g["spec_etas"]), k=float(g["spec_k"]))
+    if model == "lmasphere":
+        extra.update(sld=float(g["spec_sld"]), mf=float(g["spec_mf"]))
     m, spec = make_models(model, g["spec_lo"], g["spec_hi"], [int(x) for x in g["spec_gen"]], **extra)
     flags = dict(find_bg=bool(int(g["spec_find_bg"])) if "spec_find_bg" in g else True,
                  pos_bg=bool(int(g["spec_pos_bg"])) if "spec_pos_bg" in g else False,

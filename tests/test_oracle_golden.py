@@ -13,21 +13,11 @@ def load(name):
     return np.load(os.path.join(G, name), allow_pickle=False)
 
 
-MODEL_CASES = {
-    "sphere": dict(model="sphere", active=["radius"]),
-    "cyl_aspect": dict(model="cyl", active=["radius", "aspect"]),
-    "cyl_length": dict(model="cyl", active=["radius", "length"], useAspect=0.0),
-    "ellcs": dict(model="ellcs", active=["a", "b", "t"]),
-    "kholodenko": dict(model="kholodenko", active=["radius", "lenKuhn", "lenContour"]),
-}
+from helpers import CASES as MODEL_CASES, make_models, traj_setup as _traj_setup
 
 
 def spec_for(tag, lo=None, hi=None, gen=None, **extra):
-    c = dict(MODEL_CASES[tag]); model = c.pop("model"); active = c.pop("active")
-    c.update(extra)
-    n = len(active)
-    return O.ModelSpec.make(model, active, lo if lo is not None else [0.0] * n,
-                            hi if hi is not None else [np.inf] * n, gen, **c)
+    return make_models(tag, lo, hi, gen, **extra)[1]
 
 
 @pytest.mark.parametrize("tag", list(MODEL_CASES))
@@ -88,28 +78,14 @@ def test_g3_bgfit_leastsq_and_closed():
 
 
 def traj_setup(name):
-    g = load(name)
-    model = str(g["spec_model"])
-    extra = {}
-    if model == "sphere":
-        extra["sld"] = float(g["spec_sld"])
-    if model == "cyl_aspect":
-        extra["sld"] = float(g["spec_sld"]); extra["intDiv"] = float(g["spec_int_div"])
-    if model == "ellcs":
-        extra.update(eta_c=float(g["spec_eta_c"]), eta_s=float(g["spec_eta_s"]),
-                     eta_sol=float(g["spec_eta_sol"]), intDiv=float(g["spec_int_div"]))
-    spec = spec_for(model, g["spec_lo"], g["spec_hi"], [int(x) for x in g["spec_gen"]], **extra)
-    st = O.Settings(n_contrib=int(g["spec_n_contrib"]), n_reps=1, max_iter=int(g["spec_max_iter"]),
-                    comp_exp=float(g["spec_comp_exp"]), conv_crit=float(g["spec_conv_crit"]),
-                    find_bg=bool(int(g["spec_find_bg"])) if "spec_find_bg" in g else True,
-                    pos_bg=bool(int(g["spec_pos_bg"])) if "spec_pos_bg" in g else False,
-                    start_from_min=bool(int(g["spec_from_min"])) if "spec_from_min" in g else False)
-    return g, spec, st
+    g, m, spec, st, ost = _traj_setup(name)
+    return g, spec, ost
 
 
 TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q512_fixed.npz",
         "g4_sphere_q100_nobg.npz", "g4_sphere_q100_posbg.npz", "g4_sphere_q100_frommin.npz",
-        "g4_cyl_q40.npz", "g4_ellcs_q40.npz", "g4_kho_q24.npz"]
+        "g4_cyl_q40.npz", "g4_ellcs_q40.npz", "g4_kho_q24.npz", "g4_elliso_q40.npz", "g4_sphcs_q40.npz",
+        "g4_gausschain_q40.npz", "g4_lmasphere_q40.npz"]
 
 
 @pytest.mark.parametrize("name", TRAJ)
