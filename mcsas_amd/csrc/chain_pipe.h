@@ -66,8 +66,7 @@ struct PipeArgs {
     double *pval;                 // [R][2][kb][MAX_ACTIVE]
     int32_t *povf;                // [R][2][kb]
     int32_t *n_done;              // host-mapped: number of finished chains
-    int32_t tick;
-    int32_t pad;
+    int32_t tick, pad;            // (tick travels as its own kernel argument)
 };
 
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
@@ -607,9 +606,13 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 // ------------------------------------------------------------------------------------ one tick
 // launch t: blocks [0, R) do SCAN(t) (skipped for t < 0), the others PROD(t + 1)
 template <int M, int QPL>
-__global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs pa) {
+__global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *pap, const int tick) {
+    // The argument block lives in device memory and is read where it is needed: passed by value it
+    // would sit in SGPRs for the whole kernel (600+ bytes) and the scan loop would run on spilled
+    // scalars (one v_readlane per use).
     extern __shared__ double lds[];
-    const int R = pa.c.n_reps, b = blockIdx.x, t = pa.tick;
+    const PipeArgs &pa = *pap;
+    const int R = pa.c.n_reps, b = blockIdx.x, t = tick;
     if (b < R) {
         if (t >= 0) pipe_scan_block<QPL>(pa, lds, b, t);
     } else {
@@ -620,7 +623,8 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs pa
 
 // first tick bookkeeping: schedule records for ticks 0 and 1, counters
 template <int UNUSED>
-__global__ void pipe_reset_kernel(const PipeArgs pa) {
+__global__ void pipe_reset_kernel(const PipeArgs *pap) {
+    const PipeArgs &pa = *pap;
     const int rep = blockIdx.x * blockDim.x + threadIdx.x;
     if (rep >= pa.c.n_reps) return;
     const ChainArgs &a = pa.c;

@@ -183,6 +183,7 @@ struct mcsas_plan {
     double *d_ft = nullptr, *d_wft = nullptr, *d_dwin = nullptr, *d_scal = nullptr, *d_pval = nullptr;
     int32_t *d_slot_of = nullptr, *d_stage = nullptr, *d_povf = nullptr;
     int32_t *h_done = nullptr;          // pinned + mapped: scan kernels count finished chains into it
+    PipeArgs *d_pipeargs = nullptr;     // the argument block the tick kernels read (device copy)
     hipStream_t sP = nullptr, sS = nullptr;
     static constexpr int RING = 64;
     hipEvent_t evP[RING] = {}, evS[RING] = {};
@@ -228,7 +229,7 @@ extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     hipFree(pl->d_rset); hipFree(pl->d_cache); hipFree(pl->d_fit); hipFree(pl->d_replay); hipFree(pl->d_out);
     if (pl->h_stop) hipHostFree(pl->h_stop);
     if (pl->h_done) hipHostFree(pl->h_done);
-    hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_scal);
+    hipFree(pl->d_pipeargs); hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_scal);
     hipFree(pl->d_pval); hipFree(pl->d_slot_of); hipFree(pl->d_stage); hipFree(pl->d_povf);
     for (int i = 0; i < mcsas_plan::RING; ++i) {
         if (pl->evP[i]) hipEventDestroy(pl->evP[i]);
@@ -382,6 +383,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         PipeArgs &pa = pl->pipe;
         const size_t Kb = pa.g.kb;
         PCHK(hipMalloc(&pl->d_chains, sizeof(PipeChain) * R));
+        PCHK(hipMalloc(&pl->d_pipeargs, sizeof(PipeArgs)));
         PCHK(hipMalloc(&pl->d_ft, sizeof(double) * R * qpad)); PCHK(hipMalloc(&pl->d_wft, sizeof(double) * R * qpad));
         PCHK(hipMalloc(&pl->d_slot_of, sizeof(int32_t) * R * N)); PCHK(hipMalloc(&pl->d_stage, sizeof(int32_t) * R * 2 * Kb));
         PCHK(hipMalloc(&pl->d_dwin, sizeof(double) * R * 2 * Kb * qpad));
@@ -423,9 +425,11 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     const size_t lds = std::max(pa.g.prod_lds, pa.g.scan_lds);
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(tick, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     *pl->h_done = 0;
+    pa.tick = 0;
+    HIPCHK(hipMemcpyAsync(pl->d_pipeargs, &pa, sizeof(PipeArgs), hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(pl->ev0, st));
     {
-        void *ka[] = {(void *)&pa};
+        void *ka[] = {(void *)&pl->d_pipeargs};
         HIPCHK(hipLaunchKernel(reset, dim3((R + 63) / 64), dim3(64), ka, 0, st));
     }
     // worst case: every attempt runs to max_iter
@@ -440,8 +444,8 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
             if (pl->prob.stop && *pl->prob.stop) *pl->h_stop = 1;
             if (*(volatile int32_t *)pl->h_done >= R) break;
         }
-        pa.tick = (int32_t)t;
-        void *ka[] = {(void *)&pa};
+        int32_t tk = (int32_t)t;
+        void *ka[] = {(void *)&pl->d_pipeargs, (void *)&tk};
         HIPCHK(hipLaunchKernel(tick, grid, dim3(PIPE_BLOCK), ka, lds, st));
         if (t >= 0 && (t % 16) == 0) HIPCHK(hipEventRecord(pl->evS[(t / 16) % mcsas_plan::RING], st));
     }
