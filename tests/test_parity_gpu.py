@@ -298,3 +298,65 @@ def test_full_size_properties_other_configs(name):
         if prev is not None:
             assert (r.chisq <= prev * (1 + 1e-12)).all()
         prev = r.chisq.copy()
+
+
+EDGE = [  # (nq, n_contrib, max_iter, reps)
+    (64, 40, 130, 3), (65, 33, 97, 2), (7, 16, 50, 2), (130, 2, 40, 2), (512, 1, 10, 2), (100, 50, 0, 2),
+    (300, 200, 700, 5), (1024, 64, 90, 2),
+]
+
+
+@pytest.mark.parametrize("nq,n,steps,reps", EDGE)
+def test_edge_shapes_all_modes_agree_with_oracle(nq, n, steps, reps):
+    """Ragged q counts (padding lanes), tiny contribution counts (window does not fit -> that mode
+    must refuse, not misbehave), a single contribution (no loop, mcsas.py:354), zero iterations: every
+    execution mode that accepts the shape gives the oracle's chains."""
+    q, I, sig = _synthetic(nq)
+    m, spec = make_models("sphere", [np.pi / q.max()], [np.pi / q.min()])
+    ost = O.Settings(n_contrib=n, n_reps=1, max_iter=steps, conv_crit=1e-9)
+    ref = [O.mc_fit(spec, q, I, sig, [I.min(), I.max()], [q.min(), q.max()], ost, O.PhiloxStream(5, r), method="closed")
+           for r in range(reps)]
+    ran = 0
+    for mode in (engine.EXEC_WAVE, engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE, engine.EXEC_AUTO):
+        st = engine.Settings(n_contrib=n, n_reps=reps, max_iter=steps, conv_crit=1e-9, max_retries=0, seed=5, exec_mode=mode)
+        try:
+            res = engine.analyse(m.setup(), q, I, sig, st)
+        except mcsas_amd._lib.McSASHipError as e:
+            assert e.code == -1 and mode in (engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE)
+            continue
+        ran += 1
+        for r in range(reps):
+            assert res.num_iter[r] == ref[r].num_iter and res.num_moves[r] == ref[r].num_moves
+            np.testing.assert_allclose(res.contribs[:, :, r], ref[r].rset, rtol=1e-12)
+            np.testing.assert_allclose(res.chisq[r], ref[r].conval, rtol=1e-7)
+            np.testing.assert_allclose(res.fit[:, r], ref[r].fit, rtol=1e-7)
+    assert ran >= 2                                    # wavefront mode and auto always run
+
+
+@pytest.mark.parametrize("mode", [engine.EXEC_WAVE, engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE])
+def test_stop_word_is_honoured_in_every_mode(mode):
+    import ctypes
+    g = load("g4_sphere_q100_fixed.npz")
+    m, _ = make_models("sphere", g["spec_lo"], g["spec_hi"])
+    stop = ctypes.c_int32(1)
+    st = engine.Settings(n_contrib=100, n_reps=3, max_iter=10**9, conv_crit=0.0, max_retries=3, seed=1, exec_mode=mode)
+    res = engine.analyse(m.setup(), g["data_q"], g["data_I"], g["data_sigma"], st, stop=stop)
+    assert (res.converged == 0).all() and (res.attempts == 1).all()
+    assert (res.num_iter < 10**6).all()               # left at the first poll, not after the budget
+
+
+def test_many_reps_in_pipeline_and_replay_overflow_reporting():
+    g = load("g4_sphere_q100_fixed.npz")
+    m, _ = make_models("sphere", g["spec_lo"], g["spec_hi"])
+    st = engine.Settings(n_contrib=64, n_reps=300, max_iter=200, conv_crit=0.0, max_retries=0, seed=3,
+                         exec_mode=engine.EXEC_PIPELINE)
+    a = engine.analyse(m.setup(), g["data_q"], g["data_I"], g["data_sigma"], st)
+    st.exec_mode = engine.EXEC_WAVE
+    b = engine.analyse(m.setup(), g["data_q"], g["data_I"], g["data_sigma"], st)
+    np.testing.assert_array_equal(a.contribs, b.contribs)
+    np.testing.assert_array_equal(a.num_moves, b.num_moves)
+    for mode in (engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE):
+        st2 = engine.Settings(n_contrib=100, n_reps=1, max_iter=50, conv_crit=0.0, max_retries=0, exec_mode=mode)
+        with pytest.raises(mcsas_amd._lib.McSASHipError) as e:
+            engine.analyse(m.setup(), g["data_q"], g["data_I"], g["data_sigma"], st2, replay=g["stream"][None, :120])
+        assert e.value.code == -5
