@@ -85,11 +85,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    # one process per GPU.  MCSAS_BENCH_BACKEND=gloo lets several ranks share one card for a dry run of
+    # the multi-process path on a single-GPU box (results gathered through host memory)
+    backend = os.environ.get("MCSAS_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     use_dist = world > 1
     if use_dist:
         import torch.distributed as tdist
-        tdist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            tdist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            tdist.init_process_group(backend)
 
     q, I, sigma = synthetic_data()
     lo, hi = np.pi / q.max(), np.pi / q.min()
@@ -98,7 +106,7 @@ def main():
     n_total = args.reps * world
     first = rank * args.reps
     st = engine.Settings(n_contrib=NCONTRIB, n_reps=args.reps, max_iter=args.mc_steps, conv_crit=0.0,
-                         max_retries=0, seed=20250101, rep_offset=first, device=local_rank,
+                         max_retries=0, seed=20250101, rep_offset=first, device=dev_index,
                          waves_per_chain=args.waves, exec_mode=args.mode, debug_flags=args.debug_flags)
     plan = engine.Plan(model.setup(), q, I, sigma, st)
 
@@ -129,7 +137,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt, float(mc_steps)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(mc_steps)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         tmax = t.clone(); tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
         tsum = t.clone(); tdist.all_reduce(tsum, op=tdist.ReduceOp.SUM)
         dt, total_steps = float(tmax[0]), float(tsum[1])
@@ -165,7 +173,7 @@ def main():
         # criterion 1 is never met on this data set (every repetition then burns all 6 attempts)
         CRIT = 2.0
         stc = engine.Settings(n_contrib=NCONTRIB, n_reps=args.reps, max_iter=100000, conv_crit=CRIT, max_retries=5,
-                              seed=20250101, rep_offset=first, device=local_rank, exec_mode=args.mode)
+                              seed=20250101, rep_offset=first, device=dev_index, exec_mode=args.mode)
         t0 = time.perf_counter()
         conv = engine.analyse(model.setup(), q, I, sigma, stc)
         out["convergence_run"] = {"criterion": CRIT, "wall_s": time.perf_counter() - t0,

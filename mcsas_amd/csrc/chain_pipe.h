@@ -347,7 +347,6 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         int k = 0;
         live = ctl[2] != 0;
         if (dbg_noscan) { num_iter += kmax_all; k = kmax_all; }
-        const int g = lane & 7;
         // loop-invariant fit constants and the running sums, pinned in VGPRs (see MCSAS_IN_VGPR)
         double cSII = a.SII, cSI = a.SI, cScen = Scen, cSIoSw = SIoSw, cinvSw = invSw, cCrit = a.conv_crit, cnq = nqd;
         MCSAS_IN_VGPR(cSII); MCSAS_IN_VGPR(cSI); MCSAS_IN_VGPR(cScen); MCSAS_IN_VGPR(cSIoSw); MCSAS_IN_VGPR(cinvSw);
@@ -358,44 +357,59 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         int64_t ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
         MCSAS_STAMP_DECL(s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0, s8 = 0, s9 = 0);
+        // Steps are decided in groups: 8 after a group that accepted a move, 16 after one that did not
+        // (moves come in bursts early in a run and become rare later; a longer group amortises the fixed
+        // LDS round trips and barriers).  Wave v contributes its rows r = v (mod 8) of the group.
+        const int GMAX = (RING >= 4) ? 16 : 8;
+        int G = 8;
+        const int g16 = lane & 15;
         while (k < kmax_all && live) {
             MCSAS_STAMP(s0);
-            const int gcount = (kmax_all - k) < 8 ? (kmax_all - k) : 8;
-            // my row of this group (if any): the smallest r >= k with r = wave (mod 8)
-            const int r = k + ((wave - (k & 7) + 8) & 7);
-            const int m = r >> 3;
-            const bool mine = r < k + gcount;
+            const int gcount = (kmax_all - k) < G ? (kmax_all - k) : G;
+            // my rows of this group (if any): r0 = the smallest r >= k with r = wave (mod 8), then r0 + 8
+            const int r0 = k + ((wave - (k & 7) + 8) & 7);
+            const int m0 = r0 >> 3;
+            const bool mine = r0 < k + gcount, mine1 = r0 + 8 < k + gcount;
+            const int mlast = mine1 ? m0 + 1 : m0;
             // (rows behind the group start are normally retired and the ring refilled AFTER the barrier,
             // while the decision is being taken, so the DMA issue costs the critical path nothing; only a
             // ring too shallow to hold the next row has to catch up here)
-            while (mine && m_issue <= m && m_cur < m && !dbg_noload) {
+            while (mine && m_issue <= mlast && m_cur < m0 && !dbg_noload) {
                 ++m_cur;
                 if (m_issue < my_rows) { issue_row(m_issue); ++m_issue; }
             }
             MCSAS_STAMP(s1);
             if (mine) {
-                // wait until row m has landed: only the DMAs of younger rows may still be in flight
-                const int younger = m_issue - 1 - m;
+                // wait until my last row of the group has landed: only younger rows' DMAs may be in flight
+                const int younger = m_issue - 1 - mlast;
                 if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CALLS) : "memory");
                 else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CALLS) : "memory");
                 else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CALLS) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 MCSAS_STAMP(s2);
-                const double *dr = ring + (size_t)(m % RING) * qpad + lane;
-                double h0 = 0., h1 = 0.;
+                const double *dr = ring + (size_t)(m0 % RING) * qpad + lane;
+                const double *dr1 = ring + (size_t)((m0 + 1) % RING) * qpad + lane;
+                double h0 = 0., h1 = 0., e0 = 0., e1 = 0.;
 #pragma unroll
                 for (int j = 0; j < QPL; j += 2) {
                     h0 = fma(wftr[j], dr[WAVE * j], h0);
                     if (j + 1 < QPL) h1 = fma(wftr[j + 1], dr[WAVE * (j + 1)], h1);
                 }
-                const double hs = h0 + h1;
+                if (mine1) {
+#pragma unroll
+                    for (int j = 0; j < QPL; j += 2) {
+                        e0 = fma(wftr[j], dr1[WAVE * j], e0);
+                        if (j + 1 < QPL) e1 = fma(wftr[j + 1], dr1[WAVE * (j + 1)], e1);
+                    }
+                }
+                double hs = h0 + h1, es = e0 + e1;
                 MCSAS_STAMP(s3);
-                const double h = wave_sum(hs);
+                if (mine1) wave_sum2(hs, es); else hs = wave_sum(hs);
                 MCSAS_STAMP(s4);
-                if (lane == 0) hbuf[r - k] = h;
+                if (lane == 0) { hbuf[r0 - k] = hs; if (mine1) hbuf[r0 + 8 - k] = es; }
             }
             // the scalars of my lane's step do not depend on the other waves: fetch them before the barrier
-            const int kg = (k + g < kmax_all) ? k + g : kmax_all - 1;
+            const int kg = (k + g16 < kmax_all) ? k + g16 : kmax_all - 1;
             double sc0 = 0., sc1 = 0., sc2 = 0.;
             int ovg = 0;
             if (wave == 0) { const double *sc = ssub + kg * 4; sc0 = sc[0]; sc1 = sc[1]; sc2 = sc[2]; ovg = osub[kg]; }
@@ -412,8 +426,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 }
             }
             if (wave == 0) {
-                // lane g decides step k+g (all octets of lanes do the same work)
-                const double h = hbuf[g];
+                // lane g decides step k+g (all groups of 16 lanes do the same work)
+                const double h = hbuf[g16];
                 const double SCt = SC + sc0, SICt = SIC + sc1, SCCt = SCC + (2. * h + sc2);
                 // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
                 double S = cSII, num = SICt, den = SCCt;
@@ -422,11 +436,11 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     const bool neg_b = pos_bg && (cSI * denc - numc * SCt < 0.);
                     if (!neg_b) { S = cScen; num = numc; den = denc; }
                 }
-                const bool acc_g = (g < gcount) && (num * num > (S - X) * den);   // chi²_t < chi² (mcsas.py:379)
-                unsigned amask = (unsigned)(__ballot(acc_g) & 0xFFull);
+                const bool acc_g = (g16 < gcount) && (num * num > (S - X) * den);   // chi²_t < chi² (mcsas.py:379)
+                unsigned amask = (unsigned)(__ballot(acc_g) & 0xFFFFull);
                 if (never_accept) amask = 0u;                       // diagnostic: never accept
-                const unsigned ovm = (unsigned)(__ballot((g < gcount) && ovg) & 0xFFull);
-                int k_next, acc_row = -1;
+                const unsigned ovm = (unsigned)(__ballot((g16 < gcount) && ovg) & 0xFFFFull);
+                int k_next, acc_row = -1, g_next = GMAX;
                 if (amask == 0u) {
                     if (ovm) overflow = 1;
                     k_next = k + gcount; num_iter += gcount;
@@ -434,6 +448,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     const int ga = __builtin_ctz(amask);
                     if (ovm & ((2u << ga) - 1u)) overflow = 1;
                     acc_row = k + ga;
+                    g_next = 8;
                     SC = readlane_f64(SCt, ga); SIC = readlane_f64(SICt, ga); SCC = readlane_f64(SCCt, ga);
                     // chi²·Q of the accepted state from the same three numbers the decision used (one
                     // division); scale and background are only needed at the end of the attempt
@@ -450,7 +465,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     k_next = acc_row + 1; num_iter += ga + 1;
                     if (!(X > cCrit * cnq)) live = false;
                 }
-                if (lane == 0) { ctl[0] = k_next; ctl[1] = acc_row; ctl[2] = live ? 1 : 0; }
+                if (lane == 0) { ctl[0] = k_next; ctl[1] = acc_row; ctl[2] = live ? 1 : 0; ctl[3] = g_next; }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             MCSAS_STAMP(s7);
@@ -458,6 +473,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             MCSAS_STAMP(s8);
             const int k_next = ctl[0], acc_row = ctl[1];
             live = ctl[2] != 0;
+            G = ctl[3];
             if (wave == 0) {
                 const int m_keep = (k + ((wave - (k & 7) + 8) & 7)) >> 3;
                 while (m_cur < m_keep) {

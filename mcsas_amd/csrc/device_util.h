@@ -37,6 +37,17 @@ __device__ __forceinline__ double wave_sum(double v) {
     return readlane_f64(v, 63);
 }
 
+// two sums at once
+__device__ __forceinline__ void wave_sum2(double &a, double &b) {
+    a += dpp_f64<0xB1>(a); b += dpp_f64<0xB1>(b);
+    a += dpp_f64<0x4E>(a); b += dpp_f64<0x4E>(b);
+    a += dpp_f64<0x141>(a); b += dpp_f64<0x141>(b);
+    a += dpp_f64<0x140>(a); b += dpp_f64<0x140>(b);
+    a += dpp_f64<0x142, 0xA>(a); b += dpp_f64<0x142, 0xA>(b);
+    a += dpp_f64<0x143, 0xC>(a); b += dpp_f64<0x143, 0xC>(b);
+    a = readlane_f64(a, 63); b = readlane_f64(b, 63);
+}
+
 // three sums at once: the chains are independent so the DPP latencies interleave
 __device__ __forceinline__ void wave_sum3(double &a, double &b, double &c) {
     a += dpp_f64<0xB1>(a); b += dpp_f64<0xB1>(b); c += dpp_f64<0xB1>(c);
