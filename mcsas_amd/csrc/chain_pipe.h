@@ -72,7 +72,7 @@ struct PipeArgs {
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
 constexpr int PIPE_RING = 4;         // most rows a scan wave keeps in flight in its private LDS ring
 
-static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, PipeGeom *g) {
+static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, PipeGeom *g) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
@@ -84,6 +84,9 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, PipeGeom
     int by = n_contrib / (2 * 8 * rpw);
     if (by * 8 * rpw > 256) by = 256 / (8 * rpw);
     g->kb = by * 8 * rpw; g->qpl = qpl;
+    // rows that cost a numerical integration each (cylinders, ellipsoids, worm-like chains): one row per
+    // producer wave, so that a window is R*Kb waves for the 1024 SIMDs instead of R*Kb/8
+    if (heavy_rows) { by *= rpw; rpw = 1; }
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
     g->prod_lds = sizeof(double) * (4 * (size_t)qpad + tab_doubles);
@@ -116,7 +119,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     }
     Contrib<M>::fill_table(a.model, tab, tid, PIPE_BLOCK);
     __syncthreads();
-    const QTables qt{lq, lq3, tab};
+    const QTables qt = make_qtables<M>(a.model, lq, lq3, tab);
     double *rset = a.rset + (size_t)rep * N * P;
     double *cache = a.cache + (size_t)rep * a.cache_rows * qpad;
     const DrawSource src{a.replay ? a.replay + (size_t)rep * a.replay_len : nullptr, a.replay_len, a.seed,

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(const ChainArgs a) {
         const double qq = a.q[i];
         lq[i] = qq; lw[i] = a.w[i]; lwI[i] = a.wI[i]; lq3[i] = 1.0 / (qq * qq * qq);
     }
-    const QTables qt{lq, lq3, tab};
+    const QTables qt = make_qtables<M>(a.model, lq, lq3, tab);
     Contrib<M>::fill_table(a.model, tab, lane, WAVE);
     __syncthreads();
 

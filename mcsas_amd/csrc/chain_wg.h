@@ -120,7 +120,7 @@ __device__ __forceinline__ void wg_init_rows(const ChainArgs &a, const WgGeom &g
             if (nn >= N) break;
             const Contrib<M> c = mine.bcast(__builtin_amdgcn_readfirstlane(l));
             double it[QPL];
-            RowEval<M, QPL>::run(c, QTables{sh.lq, sh.lq3, sh.tab}, lane, it);
+            RowEval<M, QPL>::run(c, make_qtables<M>(a.model, sh.lq, sh.lq3, sh.tab), lane, it);
 #pragma unroll
             for (int j = 0; j < QPL; ++j) cache[(size_t)nn * qpad + lane + WAVE * j] = it[j];
         }
@@ -188,7 +188,7 @@ __device__ __forceinline__ void wg_producer(const ChainArgs &a, const WgGeom &g,
                     double d[QPL], nwv[QPL];
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) d[j] = orow[WAVE * j];
-                    RowEval<M, QPL>::run(cnew, QTables{sh.lq, sh.lq3, sh.tab}, lane, nwv);
+                    RowEval<M, QPL>::run(cnew, make_qtables<M>(a.model, sh.lq, sh.lq3, sh.tab), lane, nwv);
                     double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {

@@ -122,6 +122,17 @@ static int model_int_div(const mcsas_problem *p) {
     }
 }
 
+// per-wave scratch for the per-row orientation table (Contrib<M>::ROWTAB * K doubles, models.h); beyond
+// K = 256 the chain kernels evaluate the integrand directly
+static int rowtab_doubles_host(int model_id, int K) {
+    if (K > 256) return 0;
+    switch (model_id) {
+        case MCSAS_MODEL_CYL_ISO: case MCSAS_MODEL_ELL_CS: return 4 * K;
+        case MCSAS_MODEL_ELL_ISO: return 2 * K;
+        default: return 0;
+    }
+}
+
 static int fill_model_args(const mcsas_problem *p, ModelArgs *m) {
     if (p->model_id < 0 || p->model_id >= MCSAS_MODEL_COUNT) return fail(MCSAS_EINVAL, "unknown model_id %d", p->model_id);
     if (p->n_active < 1 || p->n_active > MCSAS_MAX_ACTIVE) return fail(MCSAS_EINVAL, "n_active %d out of range", p->n_active);
@@ -135,6 +146,7 @@ static int fill_model_args(const mcsas_problem *p, ModelArgs *m) {
             return fail(MCSAS_EINVAL, "active_index[%d]=%d out of range", c, p->active_index[c]);
     }
     m->int_div = model_int_div(p);
+    m->use_rowtab = rowtab_doubles_host(p->model_id, m->int_div) > 0;
     m->qmax = 0.;
     if (p->q) for (int i = 0; i < p->nq; ++i) m->qmax = std::max(m->qmax, std::fabs(p->q[i]));
     if ((p->model_id == MCSAS_MODEL_CYL_ISO || p->model_id == MCSAS_MODEL_ELL_CS || p->model_id == MCSAS_MODEL_ELL_ISO) &&
@@ -151,7 +163,6 @@ static int table_doubles_host(int model_id, int K) {
         default: return 0;
     }
 }
-
 static int select_device(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MCSAS_ENODEV, "no HIP device available");
@@ -280,7 +291,9 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     while (qpl * WAVE < p->nq) qpl *= 2;
     if (qpl > 16) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 1024 is not supported", p->nq); }
     const int qpad = qpl * WAVE;
-    const int tabd = table_doubles_host(p->model_id, margs.int_div);
+    const int tab_shared = table_doubles_host(p->model_id, margs.int_div), tab_row = rowtab_doubles_host(p->model_id, margs.int_div);
+    const bool heavy_rows = tab_shared > 0;
+#define TABD(waves_per_block) (tab_shared + (waves_per_block) * tab_row)
     // execution mode (results do not depend on it)
     int mode = p->exec_mode;
     int waves = p->waves_per_chain;
@@ -290,8 +303,8 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         else {
             PipeGeom pg; WgGeom wgm;
             if (p->n_reps >= 1024) mode = MCSAS_EXEC_WAVE;
-            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, tabd, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
-            else if (wg_geometry(p->nq, p->n_contrib, tabd, WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
+            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
+            else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
             else mode = MCSAS_EXEC_WAVE;
         }
     }
@@ -326,11 +339,11 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     // per-contribution intensity rows: the speculative kernels add two windows of spare row slots
     int cache_rows = (int)N;
     if (mode == MCSAS_EXEC_WORKGROUP) {
-        int rcg = wg_geometry(p->nq, (int)N, tabd, waves, &pl->wg);
+        int rcg = wg_geometry(p->nq, (int)N, TABD(waves), waves, &pl->wg);
         if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: needs 2*window <= n_contrib and the window in LDS (nq=%d, n_contrib=%d, waves=%d)", p->nq, (int)N, waves); }
         cache_rows = (int)N + 2 * pl->wg.window;
     } else if (mode == MCSAS_EXEC_PIPELINE) {
-        if (pipe_geometry(p->nq, (int)N, tabd, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
+        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
         cache_rows = (int)N + 2 * pl->pipe.g.kb;
     }
     size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
@@ -375,7 +388,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     a.rset = pl->d_rset; a.cache = pl->d_cache; a.cache_rows = cache_rows; a.fit = pl->d_fit; a.out = pl->d_out;
 
     if (mode == MCSAS_EXEC_WAVE) {
-        pl->lds_bytes = sizeof(double) * (4 * (size_t)qpad + tabd);
+        pl->lds_bytes = sizeof(double) * (4 * (size_t)qpad + TABD(1));
         if (!wave_kernel_for(p->model_id, qpl, use_cache)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no kernel for model %d qpl %d", p->model_id, qpl); }
     } else if (mode == MCSAS_EXEC_WORKGROUP) {
         pl->lds_bytes = pl->wg.lds_bytes;
@@ -407,6 +420,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     *out = pl;
     return MCSAS_OK;
 #undef PCHK
+#undef TABD
 }
 
 extern "C" int mcsas_hip_plan_reseed(mcsas_plan *pl, uint64_t seed, int32_t rep_offset) {

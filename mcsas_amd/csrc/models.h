@@ -19,7 +19,7 @@ struct ModelArgs {
     double  clip_hi[MCSAS_MAX_ACTIVE];
     double  comp_exp;
     int32_t int_div;       // orientation / quadrature points K (1 for the sphere)
-    int32_t pad;
+    int32_t use_rowtab;    // per-row orientation tables in LDS (host: table_doubles_host), see RowEval
     double  qmax;          // largest q of the data set: bounds q*R for the branch-free sincos
 };
 
@@ -28,6 +28,7 @@ struct QTables {
     const double *q;       // [qpad]
     const double *q3inv;   // [qpad] 1/q^3
     const double *tab;     // orientation table of the model
+    double *rowtab;        // this wave's scratch for the per-row table (ROWTAB*K doubles) or null
 };
 
 // full parameter vector for one contribution: active columns from `row`, clipped into their
@@ -52,6 +53,7 @@ template <int M> struct Contrib;
 // ---------------------------------------------------------------------------------- Sphere
 // models/sphere.py:32-63
 template <> struct Contrib<MCSAS_MODEL_SPHERE> {
+    static constexpr int ROWTAB = 0;
     double r, v, w, s, invr3;
     int fast;              // q*r < 2^20 for every q of the data set: branch-free sincos is valid
     static __device__ __forceinline__ int table_doubles(int) { return 0; }
@@ -91,8 +93,9 @@ template <> struct Contrib<MCSAS_MODEL_SPHERE> {
 // ---------------------------------------------------------------------------------- Cylinders
 // models/cylindersisotropic.py:50-101.  table: x_k (ends replaced by 0.5, :60-61) and sqrt(1-x_k^2)
 template <> struct Contrib<MCSAS_MODEL_CYL_ISO> {
+    static constexpr int ROWTAB = 4;       // per orientation k: r sqrt(1-x^2), hl x, 1/(2 r sqrt(1-x^2) hl x), 1/(r sqrt(1-x^2))
     double r, hl, v, w, s, step;
-    int K;
+    int K, fast;
     static __device__ __forceinline__ int table_doubles(int K) { return 2 * K; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &a, double *tab, int tid, int nt) {
         int K = a.int_div;
@@ -115,22 +118,71 @@ template <> struct Contrib<MCSAS_MODEL_CYL_ISO> {
         w = pow(vol, 2. * a.comp_exp);
         K = a.int_div;
         step = 1.0 / (double)(K - 1);
+        fast = (a.qmax * fmax(r, hl) < 1048576.0) && (r > 0.) && (hl > 0.);
     }
     __device__ __forceinline__ Contrib bcast(int lane) const {
         Contrib o; o.r = readlane_f64(r, lane); o.hl = readlane_f64(hl, lane);
         o.w = readlane_f64(w, lane); o.v = 0.; o.s = 0.; o.step = step; o.K = K;
+        o.fast = __builtin_amdgcn_readlane(fast, lane);
         return o;
+    }
+    // q-independent factors of the integrand, once per row (the wave's lanes share the K points)
+    __device__ __forceinline__ void fill_rowtab(const double *tab, double *rt, int lane) const {
+        for (int k = lane; k < K; k += WAVE) {
+            const double A = r * tab[K + k], B = hl * tab[k];
+            rt[4 * k + 0] = A; rt[4 * k + 1] = B;
+            rt[4 * k + 2] = 1.0 / (2. * A * B); rt[4 * k + 3] = 1.0 / A;
+        }
+    }
+    // same integral as intensity(): f_k = J1(q A_k) sin(q B_k) / (q^2 2 A_k B_k), without divisions
+    // or large-argument branches in the loop (valid when `fast`); orientation loop outside, the
+    // lane's QPL q values inside
+    template <int QPL>
+    __device__ __forceinline__ void rows_rt(const QTables &t, int lane, double (&out)[QPL]) const {
+        double q[QPL], invq[QPL], acc[QPL];
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) {
+            q[j] = t.q[lane + WAVE * j];
+            invq[j] = (q[j] * q[j]) * t.q3inv[lane + WAVE * j];
+            acc[j] = 0.;
+        }
+        const double *rt = t.rowtab;
+        for (int k = 1; k < K - 1; ++k) {
+            const double A = rt[4 * k], B = rt[4 * k + 1], C = rt[4 * k + 2], iA = rt[4 * k + 3];
+#pragma unroll
+            for (int j = 0; j < QPL; ++j) {
+                double sl, cl;
+                sincos_core(q[j] * B, &sl, &cl);
+                const double g = (j1_core(q[j] * A, invq[j] * iA) * sl) * C;
+                acc[j] = fma(g, g, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) {
+            const double qr = q[j] * r, qh = q[j] * hl;
+            const double f0 = 0.5 * (j1_fast(qr) / qr);          // end columns: analytic limits (:79-82)
+            double sq, cq;
+            sincos_core(qh, &sq, &cq);
+            const double fl = sq / qh;
+            const double iq2 = invq[j] * invq[j];
+            const double trapz = (0.5 * step) * (f0 * f0 + fl * fl + 2. * (acc[j] * (iq2 * iq2)));
+            out[j] = (16. * trapz) * w;
+        }
     }
     __device__ __forceinline__ double intensity(double q, const double *tab) const {
         // end columns: analytic limits (:79-82)
         double qr = q * r, qh = q * hl;
-        double f0 = 0.5 * (j1(qr) / qr);
-        double fl = sin(qh) / qh;
+        double f0 = 0.5 * (j1_fast(qr) / qr);
+        double sq, cq;
+        sincos_fast(qh, &sq, &cq);
+        double fl = sq / qh;
         double prev = f0 * f0, acc = 0.;
         for (int k = 1; k < K - 1; ++k) {
             double qrs = q * (r * tab[K + k]);
             double qlx = q * (2. * hl * tab[k]);
-            double f = (j1(qrs) * sin(qlx / 2.)) / (qrs * qlx);
+            double sl, cl;
+            sincos_fast(qlx / 2., &sl, &cl);
+            double f = (j1_fast(qrs) * sl) / (qrs * qlx);
             double cur = f * f;
             acc += (cur + prev);
             prev = cur;
@@ -144,8 +196,9 @@ template <> struct Contrib<MCSAS_MODEL_CYL_ISO> {
 // ---------------------------------------------------------------------------------- Core-shell ellipsoid
 // models/ellipsoidalcoreshell.py:59-97.  table: mu_k^2 and 1-mu_k^2
 template <> struct Contrib<MCSAS_MODEL_ELL_CS> {
+    static constexpr int ROWTAB = 4;       // per orientation k: R_core, R_total, 3 c1 / R_core^3, 3 c2 / R_total^3
     double a2, b2, at2, bt2, c1, c2, v, w, s, invK;
-    int K;
+    int K, fast;
     static __device__ __forceinline__ int table_doubles(int K) { return 2 * K; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &a, double *tab, int tid, int nt) {
         int K = a.int_div;
@@ -170,6 +223,7 @@ template <> struct Contrib<MCSAS_MODEL_ELL_CS> {
         w = pow(vt, 2. * ar.comp_exp);
         K = ar.int_div;
         invK = 1.0 / (double)K;
+        fast = (ar.qmax * ar.qmax * fmax(at2, bt2) < 1048576.0 * 1048576.0) && (a2 > 0.) && (b2 > 0.);
     }
     __device__ __forceinline__ Contrib bcast(int lane) const {
         Contrib o;
@@ -177,7 +231,41 @@ template <> struct Contrib<MCSAS_MODEL_ELL_CS> {
         o.at2 = readlane_f64(at2, lane); o.bt2 = readlane_f64(bt2, lane);
         o.c1 = readlane_f64(c1, lane); o.c2 = readlane_f64(c2, lane);
         o.w = readlane_f64(w, lane); o.v = 0.; o.s = 0.; o.invK = invK; o.K = K;
+        o.fast = __builtin_amdgcn_readlane(fast, lane);
         return o;
+    }
+    __device__ __forceinline__ void fill_rowtab(const double *tab, double *rt, int lane) const {
+        for (int k = lane; k < K; k += WAVE) {
+            const double m2 = tab[k], n2 = tab[K + k];
+            const double Rc = sqrt(a2 * m2 + b2 * n2), Rt = sqrt(at2 * m2 + bt2 * n2);
+            rt[4 * k + 0] = Rc; rt[4 * k + 1] = Rt;
+            rt[4 * k + 2] = (3. * c1) / (Rc * Rc * Rc); rt[4 * k + 3] = (3. * c2) / (Rt * Rt * Rt);
+        }
+    }
+    // f_k = [C1_k (sin xc - xc cos xc) + C2_k (sin xt - xt cos xt)] / q^3 with x = q R_k (valid when `fast`)
+    template <int QPL>
+    __device__ __forceinline__ void rows_rt(const QTables &t, int lane, double (&out)[QPL]) const {
+        double q[QPL], acc[QPL];
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) { q[j] = t.q[lane + WAVE * j]; acc[j] = 0.; }
+        const double *rt = t.rowtab;
+        for (int k = 0; k < K; ++k) {
+            const double Rc = rt[4 * k], Rt = rt[4 * k + 1], C1 = rt[4 * k + 2], C2 = rt[4 * k + 3];
+#pragma unroll
+            for (int j = 0; j < QPL; ++j) {
+                const double xc = q[j] * Rc, xt = q[j] * Rt;
+                double sc, cc, st, ct;
+                sincos_core(xc, &sc, &cc);
+                sincos_core(xt, &st, &ct);
+                const double g = fma(C1, fma(-xc, cc, sc), C2 * fma(-xt, ct, st));
+                acc[j] = fma(g, g, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) {
+            const double q3 = t.q3inv[lane + WAVE * j];
+            out[j] = ((acc[j] * (q3 * q3)) * invK) * w;
+        }
     }
     __device__ __forceinline__ double intensity(double q, const double *tab) const {
         double acc = 0.;
@@ -212,6 +300,7 @@ template <> struct Contrib<MCSAS_MODEL_ELL_CS> {
 // exp(-z)/(1 - exp(-2z)) replaces 1/(2 sinh z) so nothing overflows for x > 710 (the reference would).
 // table: GL-16 nodes then weights on [-1, 1].
 template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
+    static constexpr int ROWTAB = 0;
     double r, lk, x, ratio, v, w, s;
     static __device__ __forceinline__ int table_doubles(int) { return 32; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *tab, int tid, int) {
@@ -291,7 +380,7 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
         }
         const double p0 = sqrt(acc * (2.0 * invx));                      // coreIntegral (:32-37)
         const double u = q * r;
-        const double pcs = (u <= 0.) ? 1.0 : 2. * j1(u) / u;              // calcPcs (:40-45)
+        const double pcs = (u <= 0.) ? 1.0 : 2. * j1_fast(u) / u;         // calcPcs (:40-45)
         const double ff = p0 * pcs;                                       // :90
         return ff * ff * w;
     }
@@ -301,8 +390,9 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
 // models/ellipsoidsisotropic.py:51-84.  table: sin^2(alpha_k), cos^2(alpha_k), sin(alpha_k),
 // alpha = linspace(0, pi/2, K)
 template <> struct Contrib<MCSAS_MODEL_ELL_ISO> {
+    static constexpr int ROWTAB = 2;       // per orientation k: R_k, 3 sqrt(sin alpha_k) / R_k^3
     double ra2, rc2, v, w, s, invK;
-    int K;
+    int K, fast;
     static __device__ __forceinline__ int table_doubles(int K) { return 3 * K; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &a, double *tab, int tid, int nt) {
         const int K = a.int_div;
@@ -324,11 +414,42 @@ template <> struct Contrib<MCSAS_MODEL_ELL_ISO> {
         s = 0.;
         w = pow(vol, 2. * a.comp_exp);
         K = a.int_div; invK = 1.0 / (double)K;
+        fast = (a.qmax * a.qmax * fmax(ra2, rc2) < 1048576.0 * 1048576.0) && (ra2 > 0.) && (rc2 > 0.);
     }
     __device__ __forceinline__ Contrib bcast(int lane) const {
         Contrib o; o.ra2 = readlane_f64(ra2, lane); o.rc2 = readlane_f64(rc2, lane);
         o.w = readlane_f64(w, lane); o.v = 0.; o.s = 0.; o.invK = invK; o.K = K;
+        o.fast = __builtin_amdgcn_readlane(fast, lane);
         return o;
+    }
+    __device__ __forceinline__ void fill_rowtab(const double *tab, double *rt, int lane) const {
+        for (int k = lane; k < K; k += WAVE) {
+            const double R = sqrt(ra2 * tab[k] + rc2 * tab[K + k]);
+            rt[2 * k + 0] = R; rt[2 * k + 1] = (3. * sqrt(tab[2 * K + k])) / (R * R * R);
+        }
+    }
+    template <int QPL>
+    __device__ __forceinline__ void rows_rt(const QTables &t, int lane, double (&out)[QPL]) const {
+        double q[QPL], acc[QPL];
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) { q[j] = t.q[lane + WAVE * j]; acc[j] = 0.; }
+        const double *rt = t.rowtab;
+        for (int k = 0; k < K; ++k) {
+            const double R = rt[2 * k], D = rt[2 * k + 1];
+#pragma unroll
+            for (int j = 0; j < QPL; ++j) {
+                const double x = q[j] * R;
+                double sn, cs;
+                sincos_core(x, &sn, &cs);
+                const double g = D * fma(-x, cs, sn);
+                acc[j] = fma(g, g, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) {
+            const double q3 = t.q3inv[lane + WAVE * j];
+            out[j] = ((acc[j] * (q3 * q3)) * invK) * w;
+        }
     }
     __device__ __forceinline__ double intensity(double q, const double *tab) const {
         double acc = 0.;
@@ -347,6 +468,7 @@ template <> struct Contrib<MCSAS_MODEL_ELL_ISO> {
 // ---------------------------------------------------------------------------------- Core-shell sphere
 // models/sphericalcoreshell.py:50-77
 template <> struct Contrib<MCSAS_MODEL_SPH_CS> {
+    static constexpr int ROWTAB = 0;
     double r, rt, ds, dc, vr, v, w, s;
     static __device__ __forceinline__ int table_doubles(int) { return 0; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
@@ -383,6 +505,7 @@ template <> struct Contrib<MCSAS_MODEL_SPH_CS> {
 // ---------------------------------------------------------------------------------- Gaussian chain
 // models/gaussianchain.py:54-66
 template <> struct Contrib<MCSAS_MODEL_GAUSS_CHAIN> {
+    static constexpr int ROWTAB = 0;
     double rg, beta, v, w, s;
     static __device__ __forceinline__ int table_doubles(int) { return 0; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
@@ -412,6 +535,7 @@ template <> struct Contrib<MCSAS_MODEL_GAUSS_CHAIN> {
 // ---------------------------------------------------------------------------------- LMA dense spheres
 // models/lmadensesphere.py:58-106: sphere form factor times a Percus-Yevick structure factor
 template <> struct Contrib<MCSAS_MODEL_LMA_SPHERE> {
+    static constexpr int ROWTAB = 0;
     double r, rh, mu, al, be, ga, v, w, s;
     static __device__ __forceinline__ int table_doubles(int) { return 0; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
@@ -456,12 +580,38 @@ template <> struct Contrib<MCSAS_MODEL_LMA_SPHERE> {
 // ---------------------------------------------------------------------------------- row evaluation
 // out[j] = I(q[lane + 64 j]) for one contribution; the wave-uniform fast/slow choice is made once
 // per row so the QPL evaluations stay in one basic block and interleave.
+// Models with an orientation integral (ROWTAB > 0): the q-independent factors of the K integrand points
+// are worked out once per row into the wave's LDS scratch, which leaves two multiplies, the branch-free
+// sincos (and J1) and two FMAs per (q, k).
 template <int M, int QPL> struct RowEval {
     static __device__ __forceinline__ void run(const Contrib<M> &c, const QTables &t, int lane, double (&out)[QPL]) {
+        if constexpr (Contrib<M>::ROWTAB > 0) {
+            if (t.rowtab && c.fast) {
+                c.fill_rowtab(t.tab, t.rowtab, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                c.template rows_rt<QPL>(t, lane, out);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < QPL; ++j) out[j] = c.intensity(t.q[lane + WAVE * j], t.tab);
     }
 };
+
+// the block's tables as the row evaluators see them; `tab` is followed by one row scratch per wave
+template <int M>
+__device__ __forceinline__ QTables make_qtables(const ModelArgs &a, const double *q, const double *q3inv, double *tab) {
+    double *rt = nullptr;
+    if constexpr (Contrib<M>::ROWTAB > 0) {
+        if (a.use_rowtab)
+            rt = tab + Contrib<M>::table_doubles(a.int_div) + (size_t)(threadIdx.x >> 6) * Contrib<M>::ROWTAB * a.int_div;
+    }
+    return QTables{q, q3inv, tab, rt};
+}
 template <int QPL> struct RowEval<MCSAS_MODEL_SPHERE, QPL> {
     static __device__ __forceinline__ void run(const Contrib<MCSAS_MODEL_SPHERE> &c, const QTables &t, int lane,
                                                double (&out)[QPL]) {
