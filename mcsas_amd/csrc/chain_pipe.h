@@ -340,9 +340,11 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         };
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // prologue loads done before any DMA is counted
         __builtin_amdgcn_s_barrier();
-        double wftr[QPL];
+        // every wave keeps its own copy of ft and w*ft in registers and applies accepted rows to it
+        // itself (same two operations in every wave, so the copies stay bit-identical)
+        double wftr[QPL], ftr[QPL], wr[QPL];
 #pragma unroll
-        for (int j = 0; j < QPL; ++j) wftr[j] = lwft[lane + WAVE * j];
+        for (int j = 0; j < QPL; ++j) { wftr[j] = lwft[lane + WAVE * j]; ftr[j] = lft[lane + WAVE * j]; wr[j] = lw[lane + WAVE * j]; }
         const int my_rows = (kmax_all > wave) ? (kmax_all - wave + 7) / 8 : 0;   // rows this wave owns
         int m_issue = 0, m_cur = 0;
         if (!dbg_noload)
@@ -485,26 +487,20 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 }
             }
             if (acc_row >= 0) {
-                if ((acc_row & 7) == wave) {
-                    // the owner of the accepted row applies it: ft += d, w ft refreshed (mcsas.py:381-382)
-                    const double *dr = ring + (size_t)((acc_row >> 3) % RING) * qpad;
-                    double fo[QPL], dv[QPL], wv[QPL];
+                // ft += d, w ft refreshed (mcsas.py:381-382): the accepted row sits in its owner's ring,
+                // landed before B1 and not refilled before the next B1
+                const double *dr = lds + (4 + (size_t)(acc_row & 7) * RING + (size_t)((acc_row >> 3) % RING)) * qpad;
+                double dv[QPL];
 #pragma unroll
-                    for (int j = 0; j < QPL; ++j) {              // all LDS reads first, then the writes
-                        const int i = lane + WAVE * j;
-                        fo[j] = lft[i]; dv[j] = dr[i]; wv[j] = lw[i];
-                    }
+                for (int j = 0; j < QPL; ++j) dv[j] = dr[lane + WAVE * j];
 #pragma unroll
-                    for (int j = 0; j < QPL; ++j) {
-                        const int i = lane + WAVE * j;
-                        const double f = fo[j] + dv[j];
-                        lft[i] = f; lwft[i] = wv[j] * f;
-                    }
+                for (int j = 0; j < QPL; ++j) { ftr[j] += dv[j]; wftr[j] = wr[j] * ftr[j]; }
+                if (RING < 2 * (GMAX / 8)) {
+                    // a ring too shallow for a whole group refills at the top of the loop: nobody may
+                    // still be reading the accepted row then
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                          // B3
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                              // B3: new ft visible
-#pragma unroll
-                for (int j = 0; j < QPL; ++j) wftr[j] = lwft[lane + WAVE * j];
             }
             k = k_next;
 #ifdef MCSAS_STAMPS
@@ -541,7 +537,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
-                    const double f = lft[lane + WAVE * j], wf = lwft[lane + WAVE * j];
+                    const double f = ftr[j], wf = wftr[j];
                     s1 += wf; s2 += wf * f; s3 += lwI[lane + WAVE * j] * f;
                     gft[lane + WAVE * j] = f; gwft[lane + WAVE * j] = wf;
                 }
