@@ -11,7 +11,7 @@ struct ChainOut {
     int64_t num_iter, num_moves, draws, total_steps;
     int32_t attempts, converged, stream_overflow, stopped;
 #ifdef MCSAS_STAMPS
-    int64_t dbg[16];         // diagnostic build only (make EXTRA=-DMCSAS_STAMPS): s_memtime sums per phase
+    int64_t dbg[20];         // diagnostic build only (make EXTRA=-DMCSAS_STAMPS): s_memtime sums per phase
 #endif
 };
 

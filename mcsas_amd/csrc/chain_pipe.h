@@ -39,7 +39,8 @@ struct PipeChain {                // per-chain scanner state, lives in HBM betwe
     uint64_t draw_pos, t_start;
     int32_t attempts, converged, stopped, overflow, done, pad;
 #ifdef MCSAS_STAMPS
-    int64_t dbg[16];
+    int64_t dbg[20];
+    uint64_t last_end;            // wall clock (10 ns) at the end of this chain's previous scan block
 #endif
 };
 
@@ -90,11 +91,11 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
     g->prod_lds = sizeof(double) * (4 * (size_t)qpad + tab_doubles);
-    // scan block LDS: w, wI, ft, wft + one private ring of `ring` rows per wave + the window's scalars/tables
+    // scan block LDS: one private ring of `ring` rows per wave + the window's scalars/tables
     g->ks = 8; g->scan_waves = PIPE_BLOCK / 64;
     for (int ring = PIPE_RING; ring >= 1; ring /= 2) {
         g->ring = ring;
-        g->scan_lds = sizeof(double) * ((4 + (size_t)g->scan_waves * ring) * qpad + (size_t)g->kb * 4 + 16)
+        g->scan_lds = sizeof(double) * ((size_t)g->scan_waves * ring * qpad + (size_t)g->kb * 4 + 16)
                     + sizeof(int32_t) * (4 * g->kb + 32) + 64;
         if (g->scan_lds <= 160 * 1024) break;
     }
@@ -232,21 +233,25 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
 }
 
 // ------------------------------------------------------------------------------------ scanner
-// LDS: lw, lwI, lft, lwft [qpad each]; dsub[2][ks][qpad]; ssub[2][ks][4]; osub[2][ks] (int)
+// LDS: one ring of `ring` rows per wave; the window's scalars, flags and slot tables; control words
 template <int QPL>
-__device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds, int rep, int t) {
+__device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds, int rep, int t, int stop_now) {
     const ChainArgs &a = pa.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb;
     const int NW = pa.g.scan_waves, T = NW * WAVE;
     PipeChain &ch = pa.chains[rep];
     if (ch.done) return;                                      // uniform for the block
+    MCSAS_STAMP_DECL(sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0);
+    MCSAS_STAMP(sb0);
+#ifdef MCSAS_STAMPS
+    const uint64_t wc0 = wall_clock64();
+#endif
     const PipeSnap sn = ch.snap[(t + 1) & 1];                 // the record in force for tick t (written at t-1; host for t = 0)
 
-    double *lw = lds, *lwI = lds + qpad, *lft = lds + 2 * qpad, *lwft = lds + 3 * qpad;
     const int RING = pa.g.ring;
-    double *ring = lds + (4 + (size_t)wave * RING) * qpad;                 // this wave's RING rows
-    double *ssub = lds + (4 + (size_t)NW * RING) * qpad;                   // [Kb][4] scalars of the whole window
+    double *ring = lds + (size_t)wave * RING * qpad;                       // this wave's RING rows
+    double *ssub = lds + (size_t)NW * RING * qpad;                   // [Kb][4] scalars of the whole window
     double *hbuf = ssub + (size_t)Kb * 4;                                  // [8] h of the current group, by step offset
     int32_t *osub = reinterpret_cast<int32_t *>(hbuf + 16);                // [Kb] replay-overflow flags
     int32_t *lstage = osub + Kb, *lslot = lstage + Kb;          // [Kb] spare row slot of step k / row slot of its contribution
@@ -263,8 +268,6 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
     int32_t *slot_of = pa.slot_of + (size_t)rep * N;
     int32_t *stage = pa.stage_slot + ((size_t)rep * 2 + buf) * Kb;
     const double nqd = (double)a.nq;
-
-    for (int i = tid; i < qpad; i += T) { lw[i] = a.w[i]; lwI[i] = a.wI[i]; }
 
     // scanner-side chain state (meaningful in wave 0)
     FitResult cur{ch.A, ch.b, ch.chi2};
@@ -298,33 +301,15 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             if (N <= 1 || a.max_iter <= 0 || !(cur.chi2 > a.conv_crit)) attempt_over = true;
         }
     } else {
-        // ---- window w = t - t_init - 1: loaders stage sub-windows, the scanner decides
-        for (int i = tid; i < qpad; i += T) { lft[i] = gft[i]; lwft[i] = gwft[i]; }
+        // ---- window w = t - t_init - 1.  Eight symmetric waves: wave v owns the window's rows r = v (mod 8),
+        // streams them from HBM into its private LDS ring with LDS-DMA (PIPE_RING rows in flight, no
+        // registers), computes h = Σ (w ft) d for its rows of the current group of steps, and wave 0
+        // decides the group.
         const int64_t w = (int64_t)t - sn.t_init - 1;
         const int64_t budget = a.max_iter - w * Kb;
         const int kmax_all = budget < Kb ? (budget < 0 ? 0 : (int)budget) : Kb;
         const int ri0 = (int)((w * Kb) % N);
-        for (int i = tid; i < kmax_all * 4; i += T) ssub[i] = scal[i];
-        for (int i = tid; i < kmax_all; i += T) {
-            osub[i] = povf[i];
-            lstage[i] = stage[i];
-            int r = ri0 + i; if (r >= N) r -= N;
-            lslot[i] = slot_of[r];
-        }
-        if (tid == 0) lacc[Kb] = 0;
-        const double invSw = 1.0 / a.Sw, SIoSw = a.SI / a.Sw, Scen = a.SII - a.SI * a.SI / a.Sw;
-        double X = cur.chi2 * nqd;
-        bool touched = false, live = true;
-        int num_acc_win = 0;
         const bool dbg_noload = a.pad0 & 4, dbg_noscan = a.pad0 & 8;
-        if (wave == 0) {
-            __builtin_amdgcn_s_setprio(1);
-            if (a.stop_flag && __hip_atomic_load(a.stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) stopped = 1;
-            if (lane == 0) ctl[2] = (!(cur.chi2 > a.conv_crit) || stopped) ? 0 : 1;   // `live`, shared by all waves
-        }
-        // ---- eight symmetric waves.  Wave v owns the window's rows r = v (mod 8): it streams them from
-        // HBM into its private LDS ring with LDS-DMA (PIPE_RING rows in flight, no registers), computes
-        // h = Σ (w ft) d for its row of the current group of eight steps, and wave 0 decides the group.
         typedef __attribute__((address_space(3))) void *lds_vp;
         typedef __attribute__((address_space(1))) const void *glb_vp;
         constexpr int CALLS = (QPL >= 2) ? QPL / 2 : 1;        // 1 KB DMA calls per row (QPL = 1: half a call, 32 lanes)
@@ -338,17 +323,47 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     __builtin_amdgcn_global_load_lds((glb_vp)(gsrc + c * 1024), (lds_vp)(ldst + c * 128), 16, 0, 0);
             }
         };
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // prologue loads done before any DMA is counted
-        __builtin_amdgcn_s_barrier();
-        // every wave keeps its own copy of ft and w*ft in registers and applies accepted rows to it
-        // itself (same two operations in every wave, so the copies stay bit-identical)
-        double wftr[QPL], ftr[QPL], wr[QPL];
-#pragma unroll
-        for (int j = 0; j < QPL; ++j) { wftr[j] = lwft[lane + WAVE * j]; ftr[j] = lft[lane + WAVE * j]; wr[j] = lw[lane + WAVE * j]; }
+        // The whole prologue is ONE memory round trip: the first ring rows go out first, then every
+        // other load of the block, and only then the single wait.
         const int my_rows = (kmax_all > wave) ? (kmax_all - wave + 7) / 8 : 0;   // rows this wave owns
         int m_issue = 0, m_cur = 0;
         if (!dbg_noload)
             for (; m_issue < RING && m_issue < my_rows; ++m_issue) issue_row(m_issue);
+        // every wave keeps its own copy of ft, w*ft and w in registers and applies accepted rows to it
+        // itself (same two operations in every wave, so the copies stay bit-identical)
+        double wftr[QPL], ftr[QPL], wr[QPL], wIr[QPL];
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) {
+            const int i = lane + WAVE * j;
+            wr[j] = a.w[i]; wIr[j] = a.wI[i]; ftr[j] = gft[i]; wftr[j] = gwft[i];
+        }
+        {
+            const int n4 = kmax_all * 4;                       // Kb <= 256: at most two scalars per thread
+            double sv0 = 0., sv1 = 0.;
+            int ov = 0, stg = 0, sl = 0;
+            if (tid < n4) sv0 = scal[tid];
+            if (tid + PIPE_BLOCK < n4) sv1 = scal[tid + PIPE_BLOCK];
+            if (tid < kmax_all) {
+                ov = povf[tid]; stg = stage[tid];
+                int r = ri0 + tid; if (r >= N) r -= N;
+                sl = slot_of[r];
+            }
+            if (tid < n4) ssub[tid] = sv0;
+            if (tid + PIPE_BLOCK < n4) ssub[tid + PIPE_BLOCK] = sv1;
+            if (tid < kmax_all) { osub[tid] = ov; lstage[tid] = stg; lslot[tid] = sl; }
+        }
+        if (tid == 0) lacc[Kb] = 0;
+        const double invSw = 1.0 / a.Sw, SIoSw = a.SI / a.Sw, Scen = a.SII - a.SI * a.SI / a.Sw;
+        double X = cur.chi2 * nqd;
+        bool touched = false, live = true;
+        int num_acc_win = 0;
+        if (wave == 0) {
+            __builtin_amdgcn_s_setprio(1);
+            if (stop_now) stopped = 1;                         // McSAS.stop as the host saw it when it launched this tick
+            if (lane == 0) ctl[2] = (!(cur.chi2 > a.conv_crit) || stopped) ? 0 : 1;   // `live`, shared by all waves
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         int k = 0;
         live = ctl[2] != 0;
         if (dbg_noscan) { num_iter += kmax_all; k = kmax_all; }
@@ -368,6 +383,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         const int GMAX = (RING >= 4) ? 16 : 8;
         int G = 8;
         const int g16 = lane & 15;
+        MCSAS_STAMP(sb1);
         while (k < kmax_all && live) {
             MCSAS_STAMP(s0);
             const int gcount = (kmax_all - k) < G ? (kmax_all - k) : G;
@@ -489,7 +505,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             if (acc_row >= 0) {
                 // ft += d, w ft refreshed (mcsas.py:381-382): the accepted row sits in its owner's ring,
                 // landed before B1 and not refilled before the next B1
-                const double *dr = lds + (4 + (size_t)(acc_row & 7) * RING + (size_t)((acc_row >> 3) % RING)) * qpad;
+                const double *dr = lds + ((size_t)(acc_row & 7) * RING + (size_t)((acc_row >> 3) % RING)) * qpad;
                 double dv[QPL];
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) dv[j] = dr[lane + WAVE * j];
@@ -509,6 +525,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             ph[5] += s6 - s5; ph[6] += s7 - s6; ph[7] += s8 - s7; ph[8] += s9 - s8; ph[9] += s9 - s0; ph[11] += 1;
 #endif
         }
+        MCSAS_STAMP(sb2);
 #ifdef MCSAS_STAMPS
         if (wave == 0 && lane == 0) for (int i = 0; i < 12; ++i) ch.dbg[i] += ph[i];
 #endif
@@ -538,7 +555,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
                     const double f = ftr[j], wf = wftr[j];
-                    s1 += wf; s2 += wf * f; s3 += lwI[lane + WAVE * j] * f;
+                    s1 += wf; s2 += wf * f; s3 += wIr[j] * f;
                     gft[lane + WAVE * j] = f; gwft[lane + WAVE * j] = wf;
                 }
                 wave_sum3(s1, s2, s3);
@@ -594,6 +611,15 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             }
         }
         overflow = __any(overflow);
+        MCSAS_STAMP(sb3);
+#ifdef MCSAS_STAMPS
+        if (lane == 0 && sb1 != 0) { ch.dbg[12] += sb1 - sb0; ch.dbg[13] += sb3 - sb2; ch.dbg[14] += 1; ch.dbg[15] += sb3 - sb0; }
+        if (lane == 0) {
+            if (ch.last_end) { ch.dbg[16] += (int64_t)(wc0 - ch.last_end); ch.dbg[17] += 1; }
+            ch.dbg[18] += (int64_t)(wall_clock64() - wc0);
+            ch.last_end = wall_clock64();
+        }
+#endif
         if (lane == 0) {
             ch.snap[t & 1] = next;                            // read by PROD(t+2) and SCAN(t+1)
             ch.SC = SC; ch.SIC = SIC; ch.SCC = SCC; ch.A = cur.A; ch.b = cur.b; ch.chi2 = cur.chi2;
@@ -609,7 +635,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 o.total_steps = total_steps;
                 o.attempts = attempts; o.converged = converged; o.stream_overflow = ch.overflow | overflow; o.stopped = stopped;
 #ifdef MCSAS_STAMPS
-                for (int i = 0; i < 16; ++i) o.dbg[i] = ch.dbg[i];
+                for (int i = 0; i < 20; ++i) o.dbg[i] = ch.dbg[i];
 #endif
                 a.out[rep] = o;
                 __hip_atomic_fetch_add(pa.n_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -621,7 +647,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 // ------------------------------------------------------------------------------------ one tick
 // launch t: blocks [0, R) do SCAN(t) (skipped for t < 0), the others PROD(t + 1)
 template <int M, int QPL>
-__global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *pap, const int tick) {
+__global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *pap, const int tick, const int stop_now) {
     // The argument block lives in device memory and is read where it is needed: passed by value it
     // would sit in SGPRs for the whole kernel (600+ bytes) and the scan loop would run on spilled
     // scalars (one v_readlane per use).
@@ -629,7 +655,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
     const PipeArgs &pa = *pap;
     const int R = pa.c.n_reps, b = blockIdx.x, t = tick;
     if (b < R) {
-        if (t >= 0) pipe_scan_block<QPL>(pa, lds, b, t);
+        if (t >= 0) pipe_scan_block<QPL>(pa, lds, b, t, stop_now);
     } else {
         const int gy = pa.g.prod_blocks_y;
         pipe_prod_block<M, QPL>(pa, lds, (b - R) / gy, (b - R) % gy, gy, t + 1);

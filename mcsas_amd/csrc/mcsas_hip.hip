@@ -458,8 +458,8 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
             if (pl->prob.stop && *pl->prob.stop) *pl->h_stop = 1;
             if (*(volatile int32_t *)pl->h_done >= R) break;
         }
-        int32_t tk = (int32_t)t;
-        void *ka[] = {(void *)&pl->d_pipeargs, (void *)&tk};
+        int32_t tk = (int32_t)t, stop_now = (pl->prob.stop && *(volatile int32_t *)pl->prob.stop) ? 1 : 0;
+        void *ka[] = {(void *)&pl->d_pipeargs, (void *)&tk, (void *)&stop_now};
         HIPCHK(hipLaunchKernel(tick, grid, dim3(PIPE_BLOCK), ka, lds, st));
         if (t >= 0 && (t % 16) == 0) HIPCHK(hipEventRecord(pl->evS[(t / 16) % mcsas_plan::RING], st));
     }
@@ -530,11 +530,12 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
     pl->last_steps = steps;
 #ifdef MCSAS_STAMPS
     {
-        static const char *names[12] = {"retire+issue", "vmcnt wait", "lds+fma", "wave_sum", "hbuf write", "B1 wait",
-                                        "decide(+idle)", "B2 wait", "ctl read+accept", "group total", "groups(mine)", "groups"};
+        static const char *names[20] = {"retire+issue", "vmcnt wait", "lds+fma", "wave_sum", "hbuf write", "B1 wait",
+                                        "decide(+idle)", "B2 wait", "ctl read+accept", "group total", "groups(mine)", "groups",
+                                        "prologue", "epilogue", "window ticks", "block total", "gap between blocks (10ns)", "gaps", "in block (10ns)", "-"};
         for (size_t r = 0; r < R && r < 2; ++r) {
             fprintf(stderr, "[mcsas stamps] rep %zu (wave 0 cycles):", r);
-            for (int i = 0; i < 12; ++i) fprintf(stderr, " %s=%lld", names[i], (long long)ho[r].dbg[i]);
+            for (int i = 0; i < 20; ++i) fprintf(stderr, " %s=%lld", names[i], (long long)ho[r].dbg[i]);
             fprintf(stderr, "\n");
         }
     }
