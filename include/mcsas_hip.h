@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define MCSAS_ABI_VERSION 1
+#define MCSAS_ABI_VERSION 2
 #define MCSAS_MAX_ACTIVE 4   /* active (fitted) parameters per contribution: columns of rset */
 #define MCSAS_MAX_PARAMS 8   /* full parameter vector of a model */
 
@@ -118,6 +118,17 @@ typedef struct mcsas_problem {
     int32_t  waves_per_chain;    /* 0 = auto; 1 = one wavefront per chain; >1 = workgroup per chain */
     int32_t  cache_intensities;  /* -1 auto, 0 re-evaluate `old` every step like mcsas.py:362, 1 keep rows in HBM */
     int32_t  exec_mode;          /* MCSAS_EXEC_*: 0 auto, 1 wavefront per chain, 2 workgroup per chain, 3 whole-chip pipeline */
+
+    /* beam-profile smearing (ABI 2): what SASConfig.prepareSmearing left in data.locs and
+     * data.config.smearing.prepared (dataobj/sasconfig.py:308-339, dataobj/sasdata.py:165).  With
+     * smear_nk > 0 and a model whose class has canSmear = True (Sphere, LMADenseSphere) every
+     * calcIntensity is 2 * trapz(F(locs)^2 * w * weights, x = q_offset) (bases/model/sasmodel.py:56-73);
+     * other models ignore it, as in the reference.  smear_nk = 0: off. */
+    int32_t  smear_nk;               /* integration points per q (nSteps + 1, or 2 ceil(nSteps/2) + 1) */
+    int32_t  reserved1;
+    const double *smear_locs;        /* [nq][smear_nk], row-major: where F is evaluated */
+    const double *smear_q_offset;    /* [smear_nk] */
+    const double *smear_weights;     /* [smear_nk] beam-profile weights */
 } mcsas_problem;
 
 /* What mcFit returns per repetition (mcsas.py:428-439) gathered the way analyse() stores it

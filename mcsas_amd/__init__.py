@@ -12,7 +12,7 @@ from .parameter import (Parameter, FitParameter, RandomUniform, RandomExponentia
 from .scatteringmodels import (ScatteringModel, SASModel, SASModelData, Sphere,                   # noqa: F401
                                CylindersIsotropic, EllipsoidalCoreShell, Kholodenko, EllipsoidsIsotropic,
                                SphericalCoreShell, GaussianChain, LMADenseSphere, setup_from_model)
-from .dataobj import SASData                                                                      # noqa: F401
+from .dataobj import SASData, SASConfig, TrapezoidSmearing, GaussianSmearing, SmearArgs                                                                      # noqa: F401
 from .mcsas import McSAS                                                                          # noqa: F401
 
 __version__ = "0.1.0"

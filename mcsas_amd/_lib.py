@@ -13,7 +13,7 @@ import numpy as np
 
 MAX_ACTIVE = 4
 MAX_PARAMS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # MCSAS_HIP_LIB selects another build of the SAME library (e.g. the -DMCSAS_STAMPS diagnostic build)
 LIB_PATH = os.environ.get("MCSAS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmcsas_hip.so")
@@ -54,6 +54,8 @@ class Problem(C.Structure):
         ("stop", _i32p),
         ("device", C.c_int32), ("waves_per_chain", C.c_int32),
         ("cache_intensities", C.c_int32), ("exec_mode", C.c_int32),
+        ("smear_nk", C.c_int32), ("reserved1", C.c_int32),
+        ("smear_locs", _dp), ("smear_q_offset", _dp), ("smear_weights", _dp),
     ]
 
 

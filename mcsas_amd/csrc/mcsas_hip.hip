@@ -49,7 +49,12 @@ __global__ __launch_bounds__(64) void model_rows_kernel(ModelArgs m, int nq, con
     Contrib<M> c;
     c.prepare(m, row);
     if (threadIdx.x == 0) { vset[i] = c.v; wset[i] = c.w; sset[i] = c.s; }
-    for (int k = threadIdx.x; k < nq; k += WAVE) rows[(size_t)i * nq + k] = c.intensity(q[k], tab);
+    for (int k = threadIdx.x; k < nq; k += WAVE) {
+        double it;
+        if (model_can_smear(M) && m.smear_nk > 0) it = smeared_intensity<M>(c, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
+        else it = c.intensity(q[k], tab);
+        rows[(size_t)i * nq + k] = it;
+    }
 }
 
 // cumInt += it, contribution by contribution (scatteringmodel.py:101): thread per q, fixed order
@@ -105,7 +110,10 @@ __global__ __launch_bounds__(64) void observability_kernel(ModelArgs m, int nq, 
     const double vf = vol_frac[(size_t)c * R + r], A = scaling[r];
     double best = INFINITY;
     for (int k = threadIdx.x; k < nq; k += WAVE) {
-        double scaled = A * cc.intensity(q[k], tab);
+        double it;
+        if (model_can_smear(M) && m.smear_nk > 0) it = smeared_intensity<M>(cc, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
+        else it = cc.intensity(q[k], tab);
+        double scaled = A * it;
         if (scaled != 0.) best = fmin(best, (sigma[k] * vf) / scaled);
     }
     best = wave_min(best);
@@ -163,6 +171,38 @@ static int table_doubles_host(int model_id, int K) {
         default: return 0;
     }
 }
+// Device copy of the smearing tables of a problem: locs transposed to [K][stride] (pad columns repeat
+// column 0, like the padded q) and cw[m] = 2 * trapezoid coefficient(q_offset)[m] * weights[m], so that
+// sum_m cw[m] y[m] = 2 trapz(y * weights, x = q_offset) (sasmodel.py:72-73).
+struct SmearDev {
+    double *locs_t = nullptr, *cw = nullptr;
+    ~SmearDev() { if (locs_t) hipFree(locs_t); if (cw) hipFree(cw); }
+    int upload(const mcsas_problem *p, int stride, ModelArgs *m) {
+        m->smear_nk = 0; m->smear_stride = 0; m->smear_locs_t = nullptr; m->smear_cw = nullptr;
+        if (p->smear_nk <= 0) return MCSAS_OK;
+        if (!(p->model_id == MCSAS_MODEL_SPHERE || p->model_id == MCSAS_MODEL_LMA_SPHERE)) return MCSAS_OK;   // canSmear = False
+        const int K = p->smear_nk;
+        if (K < 2 || K > 4096 || !p->smear_locs || !p->smear_q_offset || !p->smear_weights)
+            return fail(MCSAS_EINVAL, "smearing: smear_nk %d (2..4096) needs locs, q_offset and weights", K);
+        std::vector<double> lt((size_t)K * stride), cw(K);
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < stride; ++i) lt[(size_t)k * stride + i] = p->smear_locs[(size_t)(i < p->nq ? i : 0) * K + k];
+        for (int k = 0; k < K; ++k) {
+            const double dl = k > 0 ? p->smear_q_offset[k] - p->smear_q_offset[k - 1] : 0.;
+            const double dr = k + 1 < K ? p->smear_q_offset[k + 1] - p->smear_q_offset[k] : 0.;
+            cw[k] = 2. * (0.5 * (dl + dr)) * p->smear_weights[k];
+        }
+        HIPCHK(hipMalloc(&locs_t, sizeof(double) * lt.size()));
+        HIPCHK(hipMalloc(&cw_dev(), sizeof(double) * K));
+        HIPCHK(hipMemcpy(locs_t, lt.data(), sizeof(double) * lt.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(this->cw, cw.data(), sizeof(double) * K, hipMemcpyHostToDevice));
+        m->smear_nk = K; m->smear_stride = stride; m->smear_locs_t = locs_t; m->smear_cw = this->cw;
+        for (size_t i = 0; i < lt.size(); ++i) m->qmax = std::max(m->qmax, std::fabs(lt[i]));
+        return MCSAS_OK;
+    }
+    double *&cw_dev() { return cw; }
+};
+
 static int select_device(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MCSAS_ENODEV, "no HIP device available");
@@ -175,6 +215,7 @@ static int select_device(int device) {
 struct mcsas_plan {
     mcsas_problem prob;
     ChainArgs args;
+    SmearDev smear;                     // device copy of the smearing tables (empty when off)
     int qpl = 0, waves = 1, use_cache = 1, dev = 0;
     size_t lds_bytes = 0;
     double *d_q = nullptr, *d_w = nullptr, *d_wI = nullptr, *d_I = nullptr;
@@ -274,6 +315,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     pl->prob = *p;
     pl->prob.q = pl->prob.intensity = pl->prob.sigma = nullptr;     // host arrays are not retained
     pl->prob.replay_stream = nullptr;
+    pl->prob.smear_locs = pl->prob.smear_q_offset = pl->prob.smear_weights = nullptr;
     hipGetDevice(&pl->dev);
 #define PCHK(expr)                                                                                   \
     do {                                                                                             \
@@ -291,8 +333,10 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     while (qpl * WAVE < p->nq) qpl *= 2;
     if (qpl > 16) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 1024 is not supported", p->nq); }
     const int qpad = qpl * WAVE;
+    rc = pl->smear.upload(p, qpad, &margs);
+    if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
     const int tab_shared = table_doubles_host(p->model_id, margs.int_div), tab_row = rowtab_doubles_host(p->model_id, margs.int_div);
-    const bool heavy_rows = tab_shared > 0;
+    const bool heavy_rows = tab_shared > 0 || margs.smear_nk > 0;
 #define TABD(waves_per_block) (tab_shared + (waves_per_block) * tab_row)
     // execution mode (results do not depend on it)
     int mode = p->exec_mode;
@@ -538,6 +582,9 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
             for (int i = 0; i < 20; ++i) fprintf(stderr, " %s=%lld", names[i], (long long)ho[r].dbg[i]);
             fprintf(stderr, "\n");
         }
+        fprintf(stderr, "[mcsas stamps] per rep: in-block us / gap us:");
+        for (size_t r = 0; r < R; ++r) fprintf(stderr, " %.0f/%.0f", ho[r].dbg[18] * 0.01, ho[r].dbg[16] * 0.01);
+        fprintf(stderr, "\n");
     }
 #endif
     if (res) {
@@ -623,6 +670,9 @@ extern "C" int mcsas_hip_model_calc(const mcsas_problem *p, const double *pset, 
     HIPCHK(dv.alloc(n)); HIPCHK(dw.alloc(n)); HIPCHK(ds.alloc(n)); HIPCHK(dc.alloc(Q));
     HIPCHK(hipMemcpy(dq.p, p->q, sizeof(double) * Q, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dp.p, pset, sizeof(double) * n * P, hipMemcpyHostToDevice));
+    SmearDev smear;
+    rc = smear.upload(p, p->nq, &m);
+    if (rc) return rc;
     size_t lds = sizeof(double) * table_doubles_host(p->model_id, m.int_div);
     switch (p->model_id) {
 #define CASE_K(mm) case mm: model_rows_kernel<mm><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
@@ -675,6 +725,9 @@ extern "C" int mcsas_hip_observability(const mcsas_problem *p, const double *con
     HIPCHK(hipMemcpy(dc.p, contribs, sizeof(double) * N * P * R, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dsc.p, scaling, sizeof(double) * R, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(dvf.p, vol_frac, sizeof(double) * N * R, hipMemcpyHostToDevice));
+    SmearDev smear;
+    rc = smear.upload(p, p->nq, &m);
+    if (rc) return rc;
     size_t lds = sizeof(double) * table_doubles_host(p->model_id, m.int_div);
     dim3 grid((unsigned)N, (unsigned)R);
     switch (p->model_id) {

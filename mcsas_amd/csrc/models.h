@@ -21,6 +21,10 @@ struct ModelArgs {
     int32_t int_div;       // orientation / quadrature points K (1 for the sphere)
     int32_t use_rowtab;    // per-row orientation tables in LDS (host: table_doubles_host), see RowEval
     double  qmax;          // largest q of the data set: bounds q*R for the branch-free sincos
+    // beam-profile smearing (sasmodel.py:56-73), canSmear models only; smear_nk = 0: off
+    int32_t smear_nk, smear_stride;    // integration points per q; row stride of locs_t (>= nq)
+    const double *smear_locs_t;        // [smear_nk][smear_stride]: evaluation points, transposed for coalescing
+    const double *smear_cw;            // [smear_nk]: 2 * trapezoid coefficient * beam-profile weight
 };
 
 // read-only per-block tables in LDS
@@ -29,7 +33,22 @@ struct QTables {
     const double *q3inv;   // [qpad] 1/q^3
     const double *tab;     // orientation table of the model
     double *rowtab;        // this wave's scratch for the per-row table (ROWTAB*K doubles) or null
+    const double *locs_t, *cw;   // smearing (ModelArgs), smear_nk = 0: off
+    int smear_nk, smear_stride;
 };
+
+template <int M> struct Contrib;
+constexpr bool model_can_smear(int m) { return m == MCSAS_MODEL_SPHERE || m == MCSAS_MODEL_LMA_SPHERE; }
+
+// smeared intensity at data point i: sum_m cw[m] * I(locs[i][m])  (I = F^2 w, so this is
+// 2 trapz(F^2 w weights, x = qOffset), sasmodel.py:72-73)
+template <int M>
+__device__ __forceinline__ double smeared_intensity(const Contrib<M> &c, const double *locs_t, const double *cw,
+                                                    int nk, int stride, int i, const double *tab) {
+    double acc = 0.;
+    for (int m = 0; m < nk; ++m) acc = fma(cw[m], c.intensity(locs_t[(size_t)m * stride + i], tab), acc);
+    return acc;
+}
 
 // full parameter vector for one contribution: active columns from `row`, clipped into their
 // valueRange as Parameter.setValue does (bases/algorithm/parameter.py:405-414,489-495)
@@ -47,8 +66,6 @@ __device__ __forceinline__ void full_params(const ModelArgs &a, const double *ro
 }
 
 constexpr double PI = 3.141592653589793;
-
-template <int M> struct Contrib;
 
 // ---------------------------------------------------------------------------------- Sphere
 // models/sphere.py:32-63
@@ -585,6 +602,14 @@ template <> struct Contrib<MCSAS_MODEL_LMA_SPHERE> {
 // sincos (and J1) and two FMAs per (q, k).
 template <int M, int QPL> struct RowEval {
     static __device__ __forceinline__ void run(const Contrib<M> &c, const QTables &t, int lane, double (&out)[QPL]) {
+        if constexpr (model_can_smear(M)) {
+            if (t.smear_nk > 0) {
+#pragma unroll
+                for (int j = 0; j < QPL; ++j)
+                    out[j] = smeared_intensity<M>(c, t.locs_t, t.cw, t.smear_nk, t.smear_stride, lane + WAVE * j, t.tab);
+                return;
+            }
+        }
         if constexpr (Contrib<M>::ROWTAB > 0) {
             if (t.rowtab && c.fast) {
                 c.fill_rowtab(t.tab, t.rowtab, lane);
@@ -610,11 +635,17 @@ __device__ __forceinline__ QTables make_qtables(const ModelArgs &a, const double
         if (a.use_rowtab)
             rt = tab + Contrib<M>::table_doubles(a.int_div) + (size_t)(threadIdx.x >> 6) * Contrib<M>::ROWTAB * a.int_div;
     }
-    return QTables{q, q3inv, tab, rt};
+    return QTables{q, q3inv, tab, rt, a.smear_locs_t, a.smear_cw, model_can_smear(M) ? a.smear_nk : 0, a.smear_stride};
 }
 template <int QPL> struct RowEval<MCSAS_MODEL_SPHERE, QPL> {
     static __device__ __forceinline__ void run(const Contrib<MCSAS_MODEL_SPHERE> &c, const QTables &t, int lane,
                                                double (&out)[QPL]) {
+        if (t.smear_nk > 0) {
+#pragma unroll
+            for (int j = 0; j < QPL; ++j)
+                out[j] = smeared_intensity<MCSAS_MODEL_SPHERE>(c, t.locs_t, t.cw, t.smear_nk, t.smear_stride, lane + WAVE * j, t.tab);
+            return;
+        }
         if (c.fast) {
 #pragma unroll
             for (int j = 0; j < QPL; ++j) out[j] = c.intensity_fast(t.q[lane + WAVE * j], t.q3inv[lane + WAVE * j]);

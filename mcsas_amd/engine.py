@@ -71,7 +71,7 @@ def _fill(arr, values, n):
 class HipProblem:
     """Owns the numpy buffers a `mcsas_problem` points at (ctypes does not keep them alive)."""
 
-    def __init__(self, model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None):
+    def __init__(self, model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None, smear=None):
         if model.n_active < 1 or model.n_active > MAX_ACTIVE:
             raise ValueError("1..%d active parameters supported, got %d" % (MAX_ACTIVE, model.n_active))
         self.q, self.I, self.sigma = f64(q).ravel(), f64(intensity).ravel(), f64(sigma).ravel()
@@ -114,6 +114,18 @@ class HipProblem:
         p.waves_per_chain = int(st.waves_per_chain)
         p.cache_intensities = int(st.cache_intensities)
         p.exec_mode = int(st.exec_mode)
+        # beam-profile smearing: `smear` carries what SASConfig.prepareSmearing produced (locs[Q][K],
+        # q_offset[K], weights[K]; dataobj.Smearing or anything with those attributes), or None
+        self.smear = None
+        if smear is not None and getattr(smear, "q_offset", None) is not None:
+            locs = f64(smear.locs)
+            if locs.ndim != 2 or locs.shape[0] != p.nq:
+                raise ValueError("smear.locs must be (nq, K), got %r" % (locs.shape,))
+            self.smear = (locs, f64(smear.q_offset).ravel(), f64(smear.weights).ravel())
+            if not (locs.shape[1] == len(self.smear[1]) == len(self.smear[2])):
+                raise ValueError("smear: locs, q_offset and weights disagree on K")
+            p.smear_nk = locs.shape[1]
+            p.smear_locs, p.smear_q_offset, p.smear_weights = (as_dp(a) for a in self.smear)
         self.c = p
 
 
@@ -140,10 +152,10 @@ class ChainResults:
         self.c = r
 
 
-def analyse(model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None) -> ChainResults:
+def analyse(model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None, smear=None) -> ChainResults:
     """All repetitions of McSAS.analyse (mcsas.py:214-262) in one kernel launch."""
     lib = _lib.load()
-    prob = HipProblem(model, q, intensity, sigma, st, replay, stop)
+    prob = HipProblem(model, q, intensity, sigma, st, replay, stop, smear)
     res = ChainResults(st.n_contrib, model.n_active, st.n_reps, len(prob.q))
     check(lib.mcsas_hip_analyse(C.byref(prob.c), C.byref(res.c)))
     return res
@@ -152,9 +164,9 @@ def analyse(model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, s
 class Plan:
     """Resident plan: data and workspaces stay in HBM; launch/fetch can be repeated (bench.py)."""
 
-    def __init__(self, model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None):
+    def __init__(self, model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None, smear=None):
         self.lib = _lib.load()
-        self.prob = HipProblem(model, q, intensity, sigma, st, replay, stop)
+        self.prob = HipProblem(model, q, intensity, sigma, st, replay, stop, smear)
         self.h = C.c_void_p()
         check(self.lib.mcsas_hip_plan_create(C.byref(self.prob.c), C.byref(self.h)))
 
@@ -203,14 +215,14 @@ class Plan:
             pass
 
 
-def model_calc(model: ModelSetup, q, pset, comp_exp, want_rows=False, device=-1):
+def model_calc(model: ModelSetup, q, pset, comp_exp, want_rows=False, device=-1, smear=None):
     """ScatteringModel.calc(data, pset, compensationExponent) (scatteringmodel.py:79-109) on the GPU.
     Returns cumInt, vset, wset, sset (and rows[n][Q] when asked)."""
     lib = _lib.load()
     q = f64(q).ravel()
     pset = f64(pset).reshape(-1, model.n_active)
     st = Settings(n_contrib=1, n_reps=1, comp_exp=comp_exp, device=device)
-    prob = HipProblem(model, q, np.ones_like(q), np.ones_like(q), st)
+    prob = HipProblem(model, q, np.ones_like(q), np.ones_like(q), st, smear=smear)
     n = len(pset)
     cum = np.zeros(len(q)); vset = np.zeros(n); wset = np.zeros(n); sset = np.zeros(n)
     rows = np.zeros((n, len(q))) if want_rows else None
@@ -229,14 +241,14 @@ def bgfit(intensity, sigma, model_int, find_background=True, positive_background
     return out[:2].copy(), float(out[2]), float(out[3])
 
 
-def observability(model: ModelSetup, q, sigma, contribs, scaling, vol_frac, comp_exp, device=-1):
+def observability(model: ModelSetup, q, sigma, contribs, scaling, vol_frac, comp_exp, device=-1, smear=None):
     """Per-contribution minimum visible volume fraction (mcsas.py:575-590) for all reps."""
     lib = _lib.load()
     contribs = f64(contribs)
     N, P, R = contribs.shape
     q = f64(q).ravel(); sigma = f64(sigma).ravel()
     st = Settings(n_contrib=N, n_reps=R, comp_exp=comp_exp, device=device)
-    prob = HipProblem(model, q, np.ones_like(q), sigma, st)
+    prob = HipProblem(model, q, np.ones_like(q), sigma, st, smear=smear)
     scaling = f64(scaling).ravel(); vol_frac = f64(vol_frac).reshape(N, R)
     out = np.zeros((N, R))
     check(lib.mcsas_hip_observability(C.byref(prob.c), as_dp(contribs), as_dp(scaling), as_dp(vol_frac), as_dp(out)))

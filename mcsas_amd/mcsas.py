@@ -112,8 +112,9 @@ class McSAS(object):
         numContribs, numReps = self.numContribs(), self.numReps()
         st = self._settings(numContribs, numReps)
         setup = setup_from_model(model, data)
+        smear = data.smearArgs(model) if hasattr(data, "smearArgs") else None   # sasmodel.py:56-60
         res = engine.analyse(setup, data.q, data.f.binnedData, data.f.binnedDataU, st,
-                             replay=replay, stop=self._stop)
+                             replay=replay, stop=self._stop, smear=smear)
         self.details = res
         if (res.converged == 0).any():                       # mcsas.py:221-230 / :240-245
             if self.stop:
@@ -149,12 +150,13 @@ class McSAS(object):
         numContribs, dummy, numReps = contribs.shape
         data, model = self.data, self.model
         setup = setup_from_model(model, data)
+        smear = data.smearArgs(model) if hasattr(data, "smearArgs") else None
         c = self.compensationExponent()
         vf = np.zeros((numContribs, numReps)); nf = np.zeros_like(vf); qf = np.zeros_like(vf); sf = np.zeros_like(vf)
         vsets = np.zeros_like(vf); ssets = np.zeros_like(vf)
         scalingFactors = np.zeros((2, numReps))
         for ri in range(numReps):
-            cum, vset, wset, sset = engine.model_calc(setup, data.q, contribs[:, :, ri], c, device=self.device)   # :552
+            cum, vset, wset, sset = engine.model_calc(setup, data.q, contribs[:, :, ri], c, device=self.device, smear=smear)   # :552
             sc, conval, _ = engine.bgfit(data.f.binnedData, data.f.binnedDataU, cum, self.findBackground.value(),
                                          self.positiveBackground.value(), setup.n_active, device=self.device)      # :559
             scalingFactors[:, ri] = sc
@@ -165,7 +167,7 @@ class McSAS(object):
             vsets[:, ri], ssets[:, ri] = vset, sset
         # observability: N single-row model evaluations per rep (:575-590), one launch for all
         sig = np.array(data.f.binnedDataU, dtype=float)
-        mv = engine.observability(setup, data.q, sig, contribs, scalingFactors[0], vf, c, device=self.device)
+        mv = engine.observability(setup, data.q, sig, contribs, scalingFactors[0], vf, c, device=self.device, smear=smear)
         mn = mv / vsets                                      # :591-594
         mq = mn * mv * mv
         ms = mn * ssets

@@ -81,7 +81,8 @@ class ScatteringModel(object):
 
     def calc(self, data, pset, compensationExponent=None):   # scatteringmodel.py:79-105, on the GPU
         q = data.q if hasattr(data, "q") else np.asarray(data)
-        cum, v, w, s = engine.model_calc(self.setup(), q, pset, compensationExponent)
+        smear = data.smearArgs(self) if hasattr(data, "smearArgs") else None    # sasmodel.py:56-60
+        cum, v, w, s = engine.model_calc(self.setup(), q, pset, compensationExponent, smear=smear)
         return self.getModelData(cum, v, w, s)
 
 

@@ -20,6 +20,9 @@ What is captured, all from the reference's own code path
       uniform stream is known (mcsas.py:191-439)
   G5  McSAS.histogram -> Histogram bins/cdf/observability/moments     (mcsas.py:445-615, utils/parameter.py)
   G6  generateParameters transforms (uniform / exponential)            (scatteringmodel.py:117-127)
+  G7  beam-profile smearing: SmearingConfig.setIntPoints, SASConfig.prepareSmearing, the smeared branch of
+      SASModel.calcIntensity and one mcFit chain on it (dataobj/sasconfig.py:17-339, sasmodel.py:56-73);
+      needs numpy.logspace's pre-1.18 float->int truncation, see _LogspaceCompat
 """
 import os, sys, tempfile, logging, re
 
@@ -540,10 +543,99 @@ def gen_analyse():
           "B consumed", out["B_consumed"])
 
 
+# ---------------------------------------------------------------- G7 (beam-profile smearing)
+class _LogspaceCompat(object):
+    """SmearingConfig.setIntPoints passes `num = numpy.ceil(n / 2.)` (a float) to numpy.logspace
+    (dataobj/sasconfig.py:133, :220).  numpy < 1.18 truncated it to int; numpy 2 raises TypeError, for
+    slit as well as pinhole collimation because that line runs first in both.  This context manager
+    gives numpy.logspace the old behaviour while the reference's smearing code runs, nothing else."""
+    def __enter__(self):
+        self._orig = np.logspace
+        def logspace(start, stop, num=50, *a, **kw):
+            return self._orig(start, stop, int(num), *a, **kw)
+        np.logspace = logspace
+        return self
+
+    def __exit__(self, *exc):
+        np.logspace = self._orig
+
+
+def gen_smearing():
+    from mcsas.dataobj.sasconfig import GaussianSmearing
+    out = {}
+    cases = (("trapz_slit", "trapezoid", False, dict(umbra=2e7, penumbra=4e7)),
+             ("trapz_pinhole", "trapezoid", True, dict(umbra=1.5e7, penumbra=5e7)),
+             ("gauss_slit", "gaussian", False, dict(variance=1.2e7)))
+    radii = (2e-9, 2.17e-8, 9e-8)
+    lma = ((1.5e-8, 0.1), (4e-8, 0.3))
+    pset = np.random.RandomState(7).uniform(3e-9, 9e-8, 12).reshape(12, 1)
+    with _LogspaceCompat():
+        for tag, kind, two_d, prm in cases:
+            d = loaddatafile("/root/reference/testdata/quickstartdemo1.csv").getDataObj()
+            if kind == "gaussian":
+                d.config.smearing = GaussianSmearing()
+                d.config.smearing.updateSmearingLimits(d.x0.binnedData)
+            sm = d.config.smearing
+            sm.doSmear.setValue(True); sm.twoDColl.setValue(two_d)
+            if kind == "trapezoid":
+                # penumbra's range follows umbra (sasconfig.py:178-182): set the larger one first
+                sm.penumbra.setValue(prm["penumbra"]); sm.umbra.setValue(prm["umbra"])
+                sm.penumbra.setValue(prm["penumbra"])
+                assert sm.umbra() == prm["umbra"] and sm.penumbra() == prm["penumbra"], (sm.umbra(), sm.penumbra())
+            else:
+                sm.variance.setValue(prm["variance"])
+                assert sm.variance() == prm["variance"]
+            assert sm.inputValid()
+            d.locs = d.config.prepareSmearing(d.x0.binnedData)       # sasdata.py:165
+            dv = data_vectors(d)
+            qoff, wts = sm.prepared
+            pre = tag + "_"
+            out[pre + "q"] = dv["q"]; out[pre + "q_offset"] = np.array(qoff, float)
+            out[pre + "weights"] = np.array(wts, float); out[pre + "locs"] = np.array(d.locs, float)
+            out[pre + "n_steps"] = int(sm.nSteps())
+            for k, v in prm.items():
+                out[pre + k] = float(v)
+            m = Sphere()
+            rows = []
+            for r in radii:
+                m.radius.setValue(r)
+                it, v, w, s = m.calcIntensity(d, compensationExponent=0.6666666)
+                rows.append(np.array(it, float))
+            out[pre + "sphere_radii"] = np.array(radii); out[pre + "sphere_it"] = np.array(rows)
+            m.radius.setActive(True)
+            md = m.calc(d, pset, 0.6666666)
+            out[pre + "sphere_pset"] = pset; out[pre + "sphere_cum"] = np.array(md.cumInt, float)
+            ml = LMADenseSphere()
+            rows = []
+            for r, vf in lma:
+                ml.radius.setValue(r); ml.volFrac.setValue(vf)
+                it, v, w, s = ml.calcIntensity(d, compensationExponent=0.6666666)
+                rows.append(np.array(it, float))
+            out[pre + "lma_params"] = np.array(lma); out[pre + "lma_it"] = np.array(rows)
+            out[pre + "lma_fixed"] = np.array([ml.mf(), ml.sld()])
+            # a model that cannot smear ignores the configuration (sasmodel.py:57)
+            mg = GaussianChain()
+            it, v, w, s = mg.calcIntensity(d, compensationExponent=0.6666666)
+            out[pre + "gauss_chain_it"] = np.array(it, float)
+            if tag == "trapz_slit":
+                # one Monte-Carlo chain on smeared intensities (mcFit with data.locs in force)
+                ms = Sphere(); ms.radius.setActiveRange(tuple(d.sphericalSizeEst()))
+                algo = new_algo(numContribs=60, numReps=1, maxIterations=500, convergenceCriterion=1e-9)
+                algo.model = ms; algo.data = d
+                spec = dict(model="sphere", n_contrib=60, lo=[min(ms.radius.activeRange())],
+                            hi=[max(ms.radius.activeRange())], gen=[0], comp_exp=0.6666666, max_iter=500,
+                            conv_crit=1e-9, sld=ms.sld())
+                save_traj("g7_sphere_q100_smeared.npz", dv, spec, run_mcfit(algo, 60, 1201),
+                          extra=dict(smear_kind="trapezoid", smear_two_d=0, smear_n_steps=int(sm.nSteps()),
+                                     smear_umbra=prm["umbra"], smear_penumbra=prm["penumbra"]))
+    np.savez_compressed(os.path.join(OUT, "g7_smearing.npz"), **out)
+    print("g7_smearing.npz", sorted(out)[:6], "...")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     quiet_logging(None)
-    which = sys.argv[1:] or ["models", "gen", "bgfit", "traj", "analyse"]
+    which = sys.argv[1:] or ["models", "gen", "bgfit", "traj", "analyse", "smear"]
     if "models" in which:
         gen_model_vectors()
     if "gen" in which:
@@ -554,3 +646,5 @@ if __name__ == "__main__":
         gen_trajectories()
     if "analyse" in which:
         gen_analyse()
+    if "smear" in which:
+        gen_smearing()

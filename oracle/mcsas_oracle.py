@@ -85,6 +85,7 @@ class ModelSpec:
     hi: np.ndarray
     gen: tuple               # GEN_* per active parameter
     values: np.ndarray       # full parameter vector (inactive entries are used as-is)
+    smear: object = None     # a prepared Smearing (data.config.smearing + data.locs) or None
 
     @property
     def n_active(self):
@@ -228,6 +229,83 @@ def ff_lma_dense_sphere(q, r, mu, mf):
     return np.sqrt(result**2 * S)
 
 
+# ----------------------------------------------------------------------------- beam-profile smearing
+CAN_SMEAR = (SPHERE, LMA_SPHERE)          # canSmear = True: models/sphere.py:15, models/lmadensesphere.py:23
+
+
+class Smearing:
+    """SmearingConfig + TrapezoidSmearing / GaussianSmearing (dataobj/sasconfig.py:17-260) and
+    SASConfig.prepareSmearing (:308-339): integration offsets qOffset[K], profile weights[K] and the
+    evaluation points locs[Q][K] of the smeared intensity (SASData.locs, dataobj/sasdata.py:165).
+
+    Quirks kept: the pinhole offsets use `ceil(n/2)` points per side (the reference passes that float
+    to numpy.logspace, which numpy < 1.18 truncated to int and numpy 2 rejects); the Gaussian profile
+    uses the parameter called `variance` as the standard deviation (scipy.stats.norm.pdf(scale=...));
+    parity of this path is pinned by tests/golden/smearing.npz, generated from the reference with
+    numpy.logspace wrapped to take that float (oracle/make_golden.py)."""
+
+    def __init__(self, kind="trapezoid", do_smear=False, n_steps=25, two_d_coll=False,
+                 umbra=0., penumbra=0., variance=0.):
+        self.kind, self.do_smear, self.n_steps, self.two_d_coll = kind, bool(do_smear), int(n_steps), bool(two_d_coll)
+        self.umbra, self.penumbra, self.variance = float(umbra), float(penumbra), float(variance)
+        self.q_offset = self.weights = self.locs = None
+
+    def input_valid(self):                                   # sasconfig.py:94-96 / :198-200
+        if self.kind == "trapezoid":
+            return self.umbra > 0. and self.penumbra > self.umbra
+        return self.variance > 0.
+
+    @property
+    def active(self):                                        # the test in sasmodel.py:56-60
+        return self.do_smear and self.input_valid() and self.q_offset is not None
+
+    @staticmethod
+    def half_trapz_pdf(x, c, d):                             # sasconfig.py:104-120
+        x = np.abs(x)
+        pdf = x * 0.
+        pdf[x < c] = 1.
+        if d > c:
+            m = (c <= x) & (x < d)
+            pdf[m] = (1. / (d - c)) * (d - x[m])
+        return pdf * (1. / (d + c))
+
+    def set_int_points(self, q):                             # sasconfig.py:122-149 / :209-233
+        n = self.n_steps
+        if self.kind == "trapezoid":
+            lo, hi = np.log10(q.min() / 5.), np.log10(self.penumbra / 2.)
+        else:
+            lo, hi = np.log10(q.min() / 3.), np.log10(2.5 * self.variance)
+        if self.two_d_coll:
+            off = np.logspace(lo, hi, num=int(np.ceil(n / 2.)))
+            off = np.concatenate((-off[::-1], [0, ], off))
+        else:
+            off = np.concatenate(([0, ], np.logspace(lo, hi, num=n)))
+        if self.kind == "trapezoid":
+            y = self.half_trapz_pdf(off, self.umbra, self.penumbra)
+        else:
+            y = np.exp(-0.5 * (off / self.variance) ** 2) / (self.variance * np.sqrt(2. * np.pi))
+        self.q_offset, self.weights = off, y
+
+    def prepare(self, q):                                    # SASConfig.prepareSmearing, sasconfig.py:308-339
+        q = np.asarray(q, dtype=float)
+        self.q_offset = self.weights = None
+        if not (self.input_valid() and self.do_smear):
+            self.locs = q
+            return q
+        self.set_int_points(q)
+        if not self.two_d_coll:
+            self.locs = np.sqrt(np.add.outer(q ** 2, self.q_offset ** 2))
+        else:
+            self.locs = np.add.outer(q, self.q_offset)
+        return self.locs
+
+
+def _trapz_x(y, x):
+    """numpy.trapz(y, x=x, axis=1)."""
+    d = np.diff(x)
+    return ((y[:, 1:] + y[:, :-1]) * d / 2.0).sum(axis=1)
+
+
 def _clip_full(spec: ModelSpec, row):
     """Full parameter vector for one contribution: active columns set from `row`, each clipped
     into its valueRange as Parameter.setValue does (bases/algorithm/parameter.py:405-414)."""
@@ -239,10 +317,16 @@ def _clip_full(spec: ModelSpec, row):
 
 
 def calc_intensity(spec: ModelSpec, q, row, comp_exp):
-    """SASModel.calcIntensity (bases/model/sasmodel.py:46-79, smearing branch off) for one
-    contribution: returns (it[Q], v, w, s) with it = F² · volume()^(2c), v = absVolume()."""
+    """SASModel.calcIntensity (bases/model/sasmodel.py:46-79) for one contribution: returns
+    (it[Q], v, w, s) with it = F² · volume()^(2c), v = absVolume(); with an active smearing
+    configuration and a canSmear model, F is evaluated at data.locs[Q][K] and
+    it = 2 · trapz(F² · w · weights, x = qOffset) (:56-73)."""
     p = _clip_full(spec, row)
     mid = spec.model_id
+    sm = spec.smear if (spec.smear is not None and spec.smear.active and mid in CAN_SMEAR) else None
+    if sm is not None:
+        assert sm.locs.shape[0] == len(q)
+        q = sm.locs
     if mid == SPHERE:
         r, sld = p
         vol = (np.pi * 4. / 3.) * r**3                         # sphere.py:39-46
@@ -296,6 +380,8 @@ def calc_intensity(spec: ModelSpec, q, row, comp_exp):
     else:
         raise ValueError("unknown model id %r" % mid)
     w = vol**(2 * comp_exp)                                    # sasmodel.py:37-44
+    if sm is not None:
+        return 2 * _trapz_x(ff**2 * w * sm.weights, sm.q_offset), v, w, s    # sasmodel.py:72-73
     return ff**2 * w, v, w, s
 
 

@@ -90,3 +90,37 @@ class FakeData(object):
     def __init__(self, q):
         class V: pass
         self.x0 = V(); self.x0.limit = [float(np.min(q)), float(np.max(q))]
+
+
+SMEAR_CASES = (("trapz_slit", "trapezoid", False), ("trapz_pinhole", "trapezoid", True), ("gauss_slit", "gaussian", False))
+
+
+def oracle_smearing(kind, two_d, n_steps, q, **widths):
+    sm = O.Smearing(kind=kind, do_smear=True, n_steps=n_steps, two_d_coll=two_d, **widths)
+    sm.prepare(q)
+    return sm
+
+
+def product_smearing(kind, two_d, n_steps, q, I=None, sigma=None, **widths):
+    """-> (SASData with the smearing configured through the mirrored config API, SmearArgs)."""
+    cfg = mcsas_amd.SASConfig(mcsas_amd.GaussianSmearing() if kind == "gaussian" else mcsas_amd.TrapezoidSmearing())
+    d = mcsas_amd.SASData(q, np.ones_like(q) if I is None else I, np.ones_like(q) if sigma is None else sigma, config=cfg)
+    sm = d.config.smearing
+    sm.doSmear.setValue(True); sm.twoDColl.setValue(two_d); sm.nSteps.setValue(n_steps)
+    if kind == "gaussian":
+        sm.variance.setValue(widths["variance"])
+    else:
+        sm.penumbra.setValue(widths["penumbra"]); sm.umbra.setValue(widths["umbra"]); sm.penumbra.setValue(widths["penumbra"])
+    d.updateConfig()
+    return d, d.smearArgs(mcsas_amd.Sphere())
+
+
+def traj_smearing(g):
+    """Smearing of a trajectory fixture (g7_*): (oracle Smearing, product SmearArgs) or (None, None)."""
+    if "smear_kind" not in g:
+        return None, None
+    kind, two_d, n = str(g["smear_kind"]), bool(int(g["smear_two_d"])), int(g["smear_n_steps"])
+    widths = {k: float(g["smear_" + k]) for k in ("umbra", "penumbra", "variance") if "smear_" + k in g}
+    osm = oracle_smearing(kind, two_d, n, g["data_q"], **widths)
+    _, psm = product_smearing(kind, two_d, n, g["data_q"], **widths)
+    return osm, psm

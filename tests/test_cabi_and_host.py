@@ -104,3 +104,42 @@ def test_sasdata_from_reference_csv(golden_dir):
     d = mcsas_amd.SASData.fromCsv(os.path.join(golden_dir, "ref_testdata", "quickstartdemo1.csv"))
     assert d.count == 101 and abs(d.q[0] - 1e7) < 1 and d.f.binnedDataU[0] == 1.89e8
     np.testing.assert_allclose(d.sphericalSizeEst(), [np.pi / 1e9, np.pi / 1e7])
+
+
+@pytest.mark.parametrize("tag,kind,two_d", [("trapz_slit", "trapezoid", False), ("trapz_pinhole", "trapezoid", True),
+                                            ("gauss_slit", "gaussian", False)])
+def test_smearing_config_mirror_prepares_what_the_reference_prepares(tag, kind, two_d, golden_dir):
+    """data.config.smearing / data.locs of the host mirror (mcsas_amd/dataobj.py) against the
+    reference's SmearingConfig.setIntPoints + SASConfig.prepareSmearing (fixture g7_smearing.npz)."""
+    from helpers import product_smearing
+    g = np.load(os.path.join(golden_dir, "g7_smearing.npz")); pre = tag + "_"
+    widths = {k: float(g[pre + k]) for k in ("umbra", "penumbra", "variance") if pre + k in g}
+    d, args = product_smearing(kind, two_d, int(g[pre + "n_steps"]), g[pre + "q"], **widths)
+    np.testing.assert_allclose(args.q_offset, g[pre + "q_offset"], rtol=1e-15)
+    np.testing.assert_allclose(args.weights, g[pre + "weights"], rtol=1e-14)
+    np.testing.assert_allclose(args.locs, g[pre + "locs"], rtol=1e-15)
+    np.testing.assert_array_equal(d.locs, args.locs)
+    # models that cannot smear, a disabled or an invalid configuration: the plain branch
+    assert d.smearArgs(mcsas_amd.GaussianChain()) is None
+    d.config.smearing.doSmear.setValue(False)
+    assert d.smearArgs(mcsas_amd.Sphere()) is None
+    d.updateConfig()
+    np.testing.assert_array_equal(d.locs, g[pre + "q"])
+    plain = mcsas_amd.SASData(g[pre + "q"], np.ones(len(g[pre + "q"])), np.ones(len(g[pre + "q"])))
+    plain.config.smearing.doSmear.setValue(True)            # umbra = penumbra = lower limit: not valid
+    assert not plain.config.smearing.inputValid() and plain.smearArgs(mcsas_amd.Sphere()) is None
+
+
+def test_smearing_value_ranges_follow_the_data():
+    """updateSmearingLimits / onUmbraUpdate (sasconfig.py:169-182): widths are clipped into
+    [min |dq|, 2 q_max] and penumbra cannot go below umbra."""
+    q = np.array([1e7, 1.5e7, 3e7, 1e8])
+    d = mcsas_amd.SASData(q, np.ones(4), np.ones(4))
+    sm = d.config.smearing
+    sm.umbra.setValue(1.0)
+    assert sm.umbra() == 5e6
+    sm.penumbra.setValue(1e12)
+    assert sm.penumbra() == 2e8
+    sm.umbra.setValue(6e7)
+    sm.penumbra.setValue(1e7)
+    assert sm.penumbra() == 6e7 and not sm.inputValid()

@@ -13,7 +13,7 @@ def load(name):
     return np.load(os.path.join(G, name), allow_pickle=False)
 
 
-from helpers import CASES as MODEL_CASES, make_models, traj_setup as _traj_setup
+from helpers import CASES as MODEL_CASES, make_models, traj_setup as _traj_setup, SMEAR_CASES, oracle_smearing, traj_smearing
 
 
 def spec_for(tag, lo=None, hi=None, gen=None, **extra):
@@ -189,3 +189,47 @@ def test_philox_known_answer():
     assert [int(x) for x in r] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
     u = O.philox_uniform(12345, 7, np.arange(1000))
     assert (u >= 0).all() and (u < 1).all() and abs(u.mean() - 0.5) < 0.05
+
+
+# ----------------------------------------------------------------------------- G7: beam-profile smearing
+def _widths(g, pre):
+    return {k: float(g[pre + k]) for k in ("umbra", "penumbra", "variance") if pre + k in g}
+
+
+@pytest.mark.parametrize("tag,kind,two_d", SMEAR_CASES)
+def test_g7_smearing_preparation_and_smeared_intensities(tag, kind, two_d):
+    """SmearingConfig.setIntPoints, SASConfig.prepareSmearing and the smeared branch of
+    SASModel.calcIntensity (sasconfig.py:122-149,209-233,308-339; sasmodel.py:56-73)."""
+    g = load("g7_smearing.npz"); pre = tag + "_"
+    q = g[pre + "q"]
+    sm = oracle_smearing(kind, two_d, int(g[pre + "n_steps"]), q, **_widths(g, pre))
+    np.testing.assert_allclose(sm.q_offset, g[pre + "q_offset"], rtol=1e-15)
+    np.testing.assert_allclose(sm.weights, g[pre + "weights"], rtol=1e-14)
+    np.testing.assert_allclose(sm.locs, g[pre + "locs"], rtol=1e-15)
+    spec = spec_for("sphere", [1e-10], [1e-6]); spec.smear = sm
+    for r, it in zip(g[pre + "sphere_radii"], g[pre + "sphere_it"]):
+        np.testing.assert_allclose(O.calc_intensity(spec, q, [r], 0.6666666)[0], it, rtol=1e-13)
+    np.testing.assert_allclose(O.model_calc(spec, q, g[pre + "sphere_pset"], 0.6666666)[0], g[pre + "sphere_cum"], rtol=1e-13)
+    mf, sld = g[pre + "lma_fixed"]
+    lspec = spec_for("lmasphere", [1e-10, 0.001], [1e-6, 0.9], mf=float(mf), sld=float(sld)); lspec.smear = sm
+    for row, it in zip(g[pre + "lma_params"], g[pre + "lma_it"]):
+        np.testing.assert_allclose(O.calc_intensity(lspec, q, row, 0.6666666)[0], it, rtol=1e-12)
+    # canSmear = False: the configuration is ignored (sasmodel.py:57)
+    gspec = spec_for("gausschain"); gspec.smear = sm
+    gspec_plain = spec_for("gausschain")
+    row = [gspec.values[i] for i in gspec.active]
+    np.testing.assert_array_equal(O.calc_intensity(gspec, q, row, 0.6666666)[0], O.calc_intensity(gspec_plain, q, row, 0.6666666)[0])
+    np.testing.assert_allclose(O.calc_intensity(gspec, q, row, 0.6666666)[0], g[pre + "gauss_chain_it"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("method", ["leastsq", "closed"])
+def test_g7_smeared_trajectory(method):
+    g, spec, st = traj_setup("g7_sphere_q100_smeared.npz")
+    spec.smear, _ = traj_smearing(g)
+    res = O.mc_fit(spec, g["data_q"], g["data_I"], g["data_sigma"], g["data_f_limit"],
+                   g["data_x0_limit"], st, O.ReplayStream(g["stream"]), method=method)
+    assert res.num_iter == int(g["res_num_iter"])
+    np.testing.assert_array_equal(np.array(res.accepted), g["res_accepted"])
+    np.testing.assert_allclose(res.rset, g["res_rset"], rtol=1e-15)
+    np.testing.assert_allclose(res.conval, float(g["res_conval"]), rtol=1e-12 if method == "leastsq" else 1e-9)
+    np.testing.assert_allclose(res.fit, g["res_fit"], rtol=1e-6)

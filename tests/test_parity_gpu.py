@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 import mcsas_amd
 from mcsas_amd import engine
 from oracle import mcsas_oracle as O
-from helpers import load, make_models, traj_setup, FakeData
+from helpers import load, make_models, traj_setup, FakeData, SMEAR_CASES, product_smearing, oracle_smearing, traj_smearing
 
 
 @pytest.mark.parametrize("tag", ["sphere", "cyl_aspect", "cyl_length", "ellcs", "kholodenko", "elliso", "sphcs",
@@ -360,3 +360,93 @@ def test_many_reps_in_pipeline_and_replay_overflow_reporting():
         with pytest.raises(mcsas_amd._lib.McSASHipError) as e:
             engine.analyse(m.setup(), g["data_q"], g["data_I"], g["data_sigma"], st2, replay=g["stream"][None, :120])
         assert e.value.code == -5
+
+
+# ----------------------------------------------------------------------------- beam-profile smearing (§8 f3)
+@pytest.mark.parametrize("tag,kind,two_d", SMEAR_CASES)
+def test_smeared_intensities_vs_reference(tag, kind, two_d):
+    """2 trapz(F(locs)^2 w weights, x = qOffset) (sasmodel.py:56-73) evaluated by the kernels against the
+    reference's values for Sphere and LMADenseSphere; a model without canSmear ignores the configuration."""
+    g = load("g7_smearing.npz"); pre = tag + "_"
+    q = g[pre + "q"]
+    widths = {k: float(g[pre + k]) for k in ("umbra", "penumbra", "variance") if pre + k in g}
+    d, args = product_smearing(kind, two_d, int(g[pre + "n_steps"]), q, **widths)
+    m, _ = make_models("sphere", [1e-10], [1e-6])
+    cum, v, w, s, rows = engine.model_calc(m.setup(), q, g[pre + "sphere_radii"][:, None], 0.6666666, want_rows=True, smear=args)
+    np.testing.assert_allclose(rows, g[pre + "sphere_it"], rtol=1e-9)
+    md = m.calc(d, g[pre + "sphere_pset"], 0.6666666)            # the plugin-API call, smearing taken from data.config
+    np.testing.assert_allclose(md.cumInt, g[pre + "sphere_cum"], rtol=1e-9)
+    mf, sld = g[pre + "lma_fixed"]
+    ml, _ = make_models("lmasphere", [1e-10, 0.001], [1e-6, 0.9], mf=float(mf), sld=float(sld))
+    rows = engine.model_calc(ml.setup(), q, g[pre + "lma_params"], 0.6666666, want_rows=True, smear=args)[4]
+    # LMA: the reference's structure-factor expression cancels catastrophically at small q*R (see
+    # test_model_calc_vs_reference_vectors); pinhole offsets put evaluation points next to q = 0, where
+    # the last ulp of sin/cos decides the 4th digit of single terms of the integrand
+    rel = np.abs(rows / g[pre + "lma_it"] - 1.)
+    assert np.median(rel) < 1e-9 and rel.max() < (2e-3 if two_d else 1e-6)
+    mg, gspec = make_models("gausschain")
+    row = np.array([[gspec.values[i] for i in gspec.active]])
+    rows = engine.model_calc(mg.setup(), q, row, 0.6666666, want_rows=True, smear=args)[4]
+    np.testing.assert_allclose(rows[0], g[pre + "gauss_chain_it"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("cache,waves", [(1, 1), (0, 1), (1, 8), (1, -3)])
+def test_smeared_trajectory_vs_reference(cache, waves):
+    g, m, spec, st, ost = traj_setup("g7_sphere_q100_smeared.npz")
+    _, psm = traj_smearing(g)
+    st.cache_intensities = cache
+    if waves == -3:
+        st.exec_mode, st.waves_per_chain = engine.EXEC_PIPELINE, 0
+    else:
+        st.waves_per_chain = waves
+    res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st,
+                         replay=g["stream"][None, :], smear=psm)
+    assert res.num_iter[0] == int(g["res_num_iter"])
+    assert res.num_moves[0] == int(g["res_num_moves"])
+    np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
+    np.testing.assert_allclose(res.chisq[0], float(g["res_conval"]), rtol=1e-7)
+    np.testing.assert_allclose(res.fit[:, 0], g["res_fit"], rtol=1e-6)
+
+
+def test_mcsas_mirror_with_smearing_matches_oracle():
+    """McSAS.calc() end to end (analyse + histogram) on slit-smeared data configured through
+    data.config.smearing, free-running Philox chains, against the oracle with the same streams."""
+    g = load("g7_smearing.npz"); pre = "trapz_slit_"
+    q = g[pre + "q"]
+    widths = dict(umbra=float(g[pre + "umbra"]), penumbra=float(g[pre + "penumbra"]))
+    osm = oracle_smearing("trapezoid", False, 25, q, **widths)
+    ospec = O.ModelSpec.make("sphere", ["radius"], [np.pi / q.max()], [np.pi / q.min()]); ospec.smear = osm
+    rs = np.random.RandomState(3)
+    truth = rs.uniform(5e-9, 6e-8, 40)[:, None]
+    I = O.model_calc(ospec, q, truth, 0.6666666)[0]
+    sig = 0.02 * I
+    I = I * (1 + 0.02 * rs.standard_normal(len(q)))
+    d, _ = product_smearing("trapezoid", False, 25, q, I, sig, **widths)
+    m = mcsas_amd.Sphere(); m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
+    m.radius.histograms().append(mcsas_amd.Histogram(m.radius, np.pi / q.max(), np.pi / q.min(), binCount=10, xscale='log', yweight='vol'))
+    st = engine.Settings(n_contrib=80, n_reps=3, max_iter=1500, conv_crit=1e-9, max_retries=0, seed=77)
+    res = engine.analyse(m.setup(d), q, I, sig, st, smear=d.smearArgs(m))
+    ost = O.Settings(n_contrib=80, n_reps=3, max_iter=1500, conv_crit=1e-9, max_retries=0)
+    for r in range(3):
+        ref = O.mc_fit(ospec, q, I, sig, d.f.limit, d.x0.limit, ost, O.PhiloxStream(77, r), method="closed")
+        assert res.num_moves[r] == ref.num_moves
+        np.testing.assert_allclose(res.contribs[:, :, r], ref.rset, rtol=1e-12)
+        np.testing.assert_allclose(res.chisq[r], ref.conval, rtol=1e-7)
+    # the algorithm object picks the configuration up from data.config by itself (maxRetries >= 1 there,
+    # mcsasparameters.json: compare with the library called with the same settings)
+    algo = mcsas_amd.McSAS(seed=77)
+    algo.numContribs.setValue(80); algo.numReps.setValue(3); algo.maxIterations.setValue(1500)
+    algo.convergenceCriterion.setValue(1e-9); algo.maxRetries.setValue(1); algo.showIncomplete.setValue(True)
+    algo.model, algo.data = m, d
+    algo.calc()
+    st.max_retries = 1
+    res1 = engine.analyse(m.setup(d), q, I, sig, st, smear=d.smearArgs(m))
+    np.testing.assert_array_equal(algo.result[0]["contribs"], res1.contribs)
+    unsmeared = engine.analyse(m.setup(d), q, I, sig, st)
+    assert not np.array_equal(unsmeared.contribs, res1.contribs)
+    # histogram(): fractions and observability from smeared model intensities (mcsas.py:549-604)
+    h = m.radius.histograms()[0]
+    fr, _ = O.fractions(ospec, q, I, sig, d.f.limit, ost, res1.contribs, method="closed")
+    np.testing.assert_allclose(algo.fractions["vol"][0], fr["vol"][0], rtol=1e-6)
+    np.testing.assert_allclose(algo.fractions["vol"][1], fr["vol"][1], rtol=1e-6)
+    assert np.isfinite(h.bins.mean).all() and np.isfinite(h.observability).all()

@@ -1,3 +1,11 @@
+#!/usr/bin/env python3
+"""One config-2 launch (50 chains x 20000 steps, pipeline mode) for diagnostics.  With the stamps
+build of the library it prints the scan block's phase shares to stderr:
+
+    make -C mcsas_amd/csrc EXTRA=-DMCSAS_STAMPS OUT=../lib/libmcsas_hip_stamps.so BUILD=../../build/csrc_stamps
+    MCSAS_HIP_LIB=$PWD/mcsas_amd/lib/libmcsas_hip_stamps.so python tools/pipeline_stamps.py
+
+Under `rocprofv3 --kernel-trace` its trace feeds tools/trace_gaps.py (tick durations and gaps)."""
 import sys, os, json
 sys.path.insert(0, os.getcwd())
 import numpy as np
