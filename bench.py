@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="waves per chain (0 = library default)")
     ap.add_argument("--mode", type=int, default=0, help="exec_mode: 0 auto, 1 wave, 2 workgroup, 3 pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-convergence-run", action="store_true",
+                    help="skip the untimed run-to-convergence (profiling: only the timed launches reach the profiler)")
     ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic role ablation (invalid results)")
     args = ap.parse_args()
 
@@ -150,7 +152,7 @@ def main():
         # HBM-side bytes per MC step from the committed PMC passes of this same command
         # (profiles/r01_pmc_summary.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); pipeline mode only
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
         if plan.info["exec_mode"] == "pipeline" and os.path.exists(tj):
             pm = json.load(open(tj))
             traffic = (pm["fetch_bytes_per_mc_step"] + pm["write_bytes_per_mc_step"]) * (mc_steps / args.steps) / launch_s / 1e9
@@ -172,14 +174,15 @@ def main():
         # noise on the synthetic curve 400 spheres plateau at chi² ~1.15 after 1e5 steps, so the default
         # criterion 1 is never met on this data set (every repetition then burns all 6 attempts)
         CRIT = 2.0
-        stc = engine.Settings(n_contrib=NCONTRIB, n_reps=args.reps, max_iter=100000, conv_crit=CRIT, max_retries=5,
-                              seed=20250101, rep_offset=first, device=dev_index, exec_mode=args.mode)
-        t0 = time.perf_counter()
-        conv = engine.analyse(model.setup(), q, I, sigma, stc)
-        out["convergence_run"] = {"criterion": CRIT, "wall_s": time.perf_counter() - t0,
-                                  "converged": int(conv.converged.sum()), "reps": args.reps,
-                                  "chisq_max": float(conv.chisq.max()), "chisq_mean": float(conv.chisq.mean()),
-                                  "steps_mean": float(conv.num_iter.mean()), "attempts_max": int(conv.attempts.max())}
+        if not args.no_convergence_run:
+            stc = engine.Settings(n_contrib=NCONTRIB, n_reps=args.reps, max_iter=100000, conv_crit=CRIT, max_retries=5,
+                                  seed=20250101, rep_offset=first, device=dev_index, exec_mode=args.mode)
+            t0 = time.perf_counter()
+            conv = engine.analyse(model.setup(), q, I, sigma, stc)
+            out["convergence_run"] = {"criterion": CRIT, "wall_s": time.perf_counter() - t0,
+                                      "converged": int(conv.converged.sum()), "reps": args.reps,
+                                      "chisq_max": float(conv.chisq.max()), "chisq_mean": float(conv.chisq.mean()),
+                                      "steps_mean": float(conv.num_iter.mean()), "attempts_max": int(conv.attempts.max())}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(q, I, sigma, lo, hi)
         print(json.dumps(out))
