@@ -190,6 +190,19 @@ int mcsas_hip_bgfit(int32_t nq, const double *intensity, const double *sigma, co
 int mcsas_hip_observability(const mcsas_problem *problem, const double *contribs,
                             const double *scaling, const double *vol_frac, double *min_req_vol);
 
+/* ---- input preparation ----------------------------------------------------------
+ * DataObj._prepareUncertainty (dataobj/dataobj.py:204-227): sigma_out = max(sigma_raw, fu_min * I),
+ * fu_min * I when sigma_raw is NULL (no uncertainty column), +inf where that is not finite. */
+int mcsas_hip_prepare_uncertainty(int32_t n, const double *intensity, const double *sigma_raw, double fu_min,
+                                  int32_t device, double *sigma_out);
+/* DataObj._reBin (dataobj/dataobj.py:288-345) on the sanitized vectors x, f, fu [n]: bin b takes the
+ * points with edges[b] <= x < edges[b+1] (edges[n_bin+1]: the caller's numpy.logspace, :312-316); one
+ * point: copied; more: mean x, mean f, max(std(f, ddof=1)/sqrt(count), sqrt(sum fu^2 / count)); empty
+ * bins are dropped.  Outputs hold up to n_bin entries, *n_out = bins kept. */
+int mcsas_hip_rebin(int32_t n, const double *x, const double *f, const double *fu, int32_t n_bin,
+                    const double *edges, int32_t device, double *x_out, double *f_out, double *fu_out,
+                    int32_t *n_out);
+
 int         mcsas_hip_device_count(void);
 int         mcsas_hip_abi_version(void);
 const char *mcsas_hip_last_error(void);

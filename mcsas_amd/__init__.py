@@ -13,6 +13,7 @@ from .scatteringmodels import (ScatteringModel, SASModel, SASModelData, Sphere, 
                                CylindersIsotropic, EllipsoidalCoreShell, Kholodenko, EllipsoidsIsotropic,
                                SphericalCoreShell, GaussianChain, LMADenseSphere, setup_from_model)
 from .dataobj import SASData, SASConfig, TrapezoidSmearing, GaussianSmearing, SmearArgs                                                                      # noqa: F401
+from .series import run_series                                                                    # noqa: F401
 from .mcsas import McSAS                                                                          # noqa: F401
 
 __version__ = "0.1.0"

@@ -120,6 +120,49 @@ __global__ __launch_bounds__(64) void observability_kernel(ModelArgs m, int nq, 
     if (threadIdx.x == 0) min_req[(size_t)c * R + r] = best;
 }
 
+// ------------------------------------------------------------------------------ input preparation
+// DataObj._prepareUncertainty (dataobj/dataobj.py:204-227)
+__global__ void prepare_uncertainty_kernel(int n, const double *I, const double *su, double fu_min, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double floor_u = fu_min * I[i];
+    double u = su ? fmax(su[i], floor_u) : floor_u;          // numpy.maximum propagates NaN; fmax would not:
+    if (su && (su[i] != su[i] || floor_u != floor_u)) u = NAN;
+    out[i] = isfinite(u) ? u : INFINITY;
+}
+
+// DataObj._reBin (dataobj/dataobj.py:319-337): one wavefront per bin
+__global__ __launch_bounds__(64) void rebin_kernel(int n, const double *x, const double *f, const double *fu,
+                                                   const double *edges, double *xb, double *fb, double *ub, int32_t *cnt_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const double lo = edges[b], hi = edges[b + 1];
+    double cnt = 0., sx = 0., sf = 0., su2 = 0., x1 = 0., f1 = 0., u1 = 0.;
+    for (int i = lane; i < n; i += WAVE) {
+        const double xi = x[i];
+        if (xi >= lo && xi < hi) { cnt += 1.; sx += xi; sf += f[i]; su2 += fu[i] * fu[i]; x1 = xi; f1 = f[i]; u1 = fu[i]; }
+    }
+    const double mine = cnt;
+    cnt = wave_sum(cnt); sx = wave_sum(sx); sf = wave_sum(sf); su2 = wave_sum(su2);
+    const int c = (int)cnt;
+    if (c == 1) {                                          // the lane that holds the point copies it (:327-329)
+        if (mine == 1.) { xb[b] = x1; fb[b] = f1; ub[b] = u1; }
+    } else if (c > 1) {
+        const double mf = sf / cnt;
+        double ss = 0.;
+        for (int i = lane; i < n; i += WAVE) {
+            const double xi = x[i];
+            if (xi >= lo && xi < hi) { const double dlt = f[i] - mf; ss += dlt * dlt; }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) {
+            xb[b] = sx / cnt; fb[b] = mf;
+            const double sem = sqrt(ss / (cnt - 1.)) / sqrt(cnt), prop = sqrt(su2 / cnt);
+            ub[b] = (sem != sem || prop != prop) ? NAN : fmax(sem, prop);     // numpy.maximum
+        }
+    }
+    if (lane == 0) cnt_out[b] = c;
+}
+
 // ------------------------------------------------------------------------------ host helpers
 static int model_int_div(const mcsas_problem *p) {
     switch (p->model_id) {
@@ -738,6 +781,51 @@ extern "C" int mcsas_hip_observability(const mcsas_problem *p, const double *con
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(min_req_vol, dm.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_prepare_uncertainty(int32_t n, const double *intensity, const double *sigma_raw, double fu_min,
+                                             int32_t device, double *sigma_out) {
+    if (n < 1 || !intensity || !sigma_out) return fail(MCSAS_EINVAL, "bad argument");
+    int rc = select_device(device);
+    if (rc) return rc;
+    DevBuf<double> dI, dS, dO;
+    HIPCHK(dI.alloc(n)); HIPCHK(dO.alloc(n));
+    HIPCHK(hipMemcpy(dI.p, intensity, sizeof(double) * n, hipMemcpyHostToDevice));
+    if (sigma_raw) { HIPCHK(dS.alloc(n)); HIPCHK(hipMemcpy(dS.p, sigma_raw, sizeof(double) * n, hipMemcpyHostToDevice)); }
+    prepare_uncertainty_kernel<<<(n + 255) / 256, 256>>>(n, dI.p, sigma_raw ? dS.p : nullptr, fu_min, dO.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(sigma_out, dO.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_rebin(int32_t n, const double *x, const double *f, const double *fu, int32_t n_bin,
+                               const double *edges, int32_t device, double *x_out, double *f_out, double *fu_out,
+                               int32_t *n_out) {
+    if (n < 1 || n_bin < 1 || n_bin > 1000000 || !x || !f || !fu || !edges || !x_out || !f_out || !fu_out || !n_out)
+        return fail(MCSAS_EINVAL, "bad argument");
+    int rc = select_device(device);
+    if (rc) return rc;
+    DevBuf<double> dx, df, du, de, bx, bf, bu;
+    DevBuf<int32_t> bc;
+    HIPCHK(dx.alloc(n)); HIPCHK(df.alloc(n)); HIPCHK(du.alloc(n)); HIPCHK(de.alloc(n_bin + 1));
+    HIPCHK(bx.alloc(n_bin)); HIPCHK(bf.alloc(n_bin)); HIPCHK(bu.alloc(n_bin)); HIPCHK(bc.alloc(n_bin));
+    HIPCHK(hipMemcpy(dx.p, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(df.p, f, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(du.p, fu, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(de.p, edges, sizeof(double) * (n_bin + 1), hipMemcpyHostToDevice));
+    rebin_kernel<<<n_bin, WAVE>>>(n, dx.p, df.p, du.p, de.p, bx.p, bf.p, bu.p, bc.p);
+    HIPCHK(hipGetLastError());
+    std::vector<double> hx(n_bin), hf(n_bin), hu(n_bin);
+    std::vector<int32_t> hc(n_bin);
+    HIPCHK(hipMemcpy(hx.data(), bx.p, sizeof(double) * n_bin, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hf.data(), bf.p, sizeof(double) * n_bin, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hu.data(), bu.p, sizeof(double) * n_bin, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hc.data(), bc.p, sizeof(int32_t) * n_bin, hipMemcpyDeviceToHost));
+    int32_t k = 0;
+    for (int b = 0; b < n_bin; ++b)                               // empty bins (and NaN means) are dropped (:339-341)
+        if (hc[b] > 0 && hf[b] == hf[b]) { x_out[k] = hx[b]; f_out[k] = hf[b]; fu_out[k] = hu[b]; ++k; }
+    *n_out = k;
     return MCSAS_OK;
 }
 

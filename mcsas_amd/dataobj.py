@@ -218,6 +218,23 @@ class SASData(object):
         return np.array([np.pi / self.x0.limit[1], np.pi / self.x0.limit[0]])
 
     @classmethod
+    def fromRaw(cls, q, intensity, sigma=None, nBin=100, fuMin=0.01, title="data", device=-1):
+        """Raw SI vectors -> the data object McSAS.analyse reads, the way DataObj prepares it
+        (dataobj/dataobj.py): uncertainty floor fuMin*I (_prepareUncertainty, :204-227), points with
+        q <= 0 or non-finite entries dropped (the default masks, :239-263), then log-spaced rebinning into
+        at most nBin bins (_reBin, :288-345; nBin = 0: none).  Both steps run on the GPU
+        (mcsas_hip_prepare_uncertainty, mcsas_hip_rebin)."""
+        from . import engine
+        q, intensity = np.asarray(q, dtype=float), np.asarray(intensity, dtype=float)
+        su = engine.prepare_uncertainty(intensity, sigma, fuMin, device=device)
+        ok = np.isfinite(q) & (q > 0.) & np.isfinite(intensity)
+        qs, fs, us = q[ok], intensity[ok], su[ok]
+        f_limit = [float(fs.min()), float(fs.max())]         # limits of the un-binned intensities (datavector.py:52)
+        if nBin and nBin > 0:
+            qs, fs, us = engine.rebin(qs, fs, us, int(nBin), device=device)
+        return cls(qs, fs, us, f_limit=f_limit, title=title)
+
+    @classmethod
     def fromCsv(cls, filename, q_unit=1e9):
         raw = open(filename, "rb").read().decode("utf-8", "replace").replace("\r", "\n")
         rows = []

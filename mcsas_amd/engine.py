@@ -255,5 +255,30 @@ def observability(model: ModelSetup, q, sigma, contribs, scaling, vol_frac, comp
     return out
 
 
+def prepare_uncertainty(intensity, sigma_raw, fu_min, device=-1):
+    """DataObj._prepareUncertainty (dataobj/dataobj.py:204-227) on the GPU."""
+    lib = _lib.load()
+    I = f64(intensity).ravel()
+    su = None if sigma_raw is None else f64(sigma_raw).ravel()
+    out = np.zeros(len(I))
+    check(lib.mcsas_hip_prepare_uncertainty(len(I), as_dp(I), as_dp(su) if su is not None else None, float(fu_min),
+                                            int(device), as_dp(out)))
+    return out
+
+
+def rebin(x, f, fu, n_bin, device=-1):
+    """DataObj._reBin (dataobj/dataobj.py:288-345) on the GPU: (x_binned, f_binned, fu_binned).  The
+    log-spaced edges are the reference's numpy expression (:312-316), evaluated here on the host."""
+    lib = _lib.load()
+    x, f, fu = f64(x).ravel(), f64(f).ravel(), f64(fu).ravel()
+    n_bin = int(n_bin)
+    edges = np.logspace(np.log10(x.min()), np.log10(x.max() + np.diff(x)[-1] / 100.), n_bin + 1)
+    xo, fo, uo = np.zeros(n_bin), np.zeros(n_bin), np.zeros(n_bin)
+    k = C.c_int32(0)
+    check(lib.mcsas_hip_rebin(len(x), as_dp(x), as_dp(f), as_dp(fu), n_bin, as_dp(edges), int(device),
+                              as_dp(xo), as_dp(fo), as_dp(uo), C.byref(k)))
+    return xo[:k.value].copy(), fo[:k.value].copy(), uo[:k.value].copy()
+
+
 def device_count():
     return _lib.load().mcsas_hip_device_count()

@@ -23,6 +23,7 @@ What is captured, all from the reference's own code path
   G7  beam-profile smearing: SmearingConfig.setIntPoints, SASConfig.prepareSmearing, the smeared branch of
       SASModel.calcIntensity and one mcFit chain on it (dataobj/sasconfig.py:17-339, sasmodel.py:56-73);
       needs numpy.logspace's pre-1.18 float->int truncation, see _LogspaceCompat
+  G8  input preparation: DataObj._prepareUncertainty and DataObj._reBin (dataobj/dataobj.py:204-227,288-345)
 """
 import os, sys, tempfile, logging, re
 
@@ -632,10 +633,42 @@ def gen_smearing():
     print("g7_smearing.npz", sorted(out)[:6], "...")
 
 
+# ---------------------------------------------------------------- G8 (input preparation)
+def gen_input_prep():
+    out = {}
+    rs = np.random.RandomState(11)
+    # (a) the reference's demo file, default 100 bins; (b) a dense synthetic curve, 60 bins, with
+    # bins of 1, 2 and many points, a missing uncertainty column and a non-finite uncertainty
+    d = loaddatafile("/root/reference/testdata/quickstartdemo1.csv").getDataObj()
+    q_nm = np.sort(np.concatenate([np.logspace(-2, 0.4, 1400), np.linspace(0.0101, 0.0109, 3)]))
+    I = 1e3 * q_nm ** -3.2 * (1 + 0.05 * rs.standard_normal(len(q_nm))) + 2.0
+    sig = 0.02 * I * rs.uniform(0.2, 3.0, len(q_nm))
+    sig[17] = np.inf
+    d2 = SASData(title="dense", rawArray=np.stack([q_nm, I, sig], axis=1))
+    for tag, dd, nb in (("demo", d, 100), ("dense", d2, 60)):
+        dd.config.nBin.setValue(nb)
+        dd._prepareUncertainty()                      # what the fuMin callback runs (dataobj.py:175, dataconfig.py:117)
+        dd._propagateMask()
+        dd._reBin()
+        out[tag + "_nbin"] = nb
+        out[tag + "_fu_min"] = float(dd.config.fuMin())
+        out[tag + "_raw_f"] = np.array(dd.f.siData, float)
+        out[tag + "_raw_fu"] = np.array(dd.f.unit.toSi(dd.f.rawDataU), float)
+        out[tag + "_si_fu"] = np.array(dd.f.siDataU, float)
+        out[tag + "_san_x"] = np.array(dd.x0.sanitized, float)
+        out[tag + "_san_f"] = np.array(dd.f.sanitized, float)
+        out[tag + "_san_fu"] = np.array(dd.f.sanitizedU, float)
+        out[tag + "_bin_x"] = np.array(dd.x0.binnedData, float)
+        out[tag + "_bin_f"] = np.array(dd.f.binnedData, float)
+        out[tag + "_bin_fu"] = np.array(dd.f.binnedDataU, float)
+        print("g8", tag, "sanitized", len(dd.x0.sanitized), "->", len(dd.x0.binnedData), "bins")
+    np.savez_compressed(os.path.join(OUT, "g8_input_prep.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     quiet_logging(None)
-    which = sys.argv[1:] or ["models", "gen", "bgfit", "traj", "analyse", "smear"]
+    which = sys.argv[1:] or ["models", "gen", "bgfit", "traj", "analyse", "smear", "prep"]
     if "models" in which:
         gen_model_vectors()
     if "gen" in which:
@@ -648,3 +681,5 @@ if __name__ == "__main__":
         gen_analyse()
     if "smear" in which:
         gen_smearing()
+    if "prep" in which:
+        gen_input_prep()

@@ -764,3 +764,45 @@ def histogram_calc(contribs, param_index, frac, lower, upper, bin_count, xscale=
                 bins_std=bins_full.std(axis=1, ddof=ddof), cdf_mean=cdf_full.mean(axis=1),
                 cdf_std=cdf_full.std(axis=1, ddof=ddof), observability=observ,
                 moments=np.array(moments))
+
+
+# ----------------------------------------------------------------------------- input preparation
+def prepare_uncertainty(intensity, sigma_raw, fu_min):
+    """DataObj._prepareUncertainty (dataobj/dataobj.py:204-227): uncertainties are raised to at least
+    fu_min * intensity; without an uncertainty column that floor is used; non-finite entries become inf."""
+    intensity = np.asarray(intensity, dtype=float)
+    floor = fu_min * intensity
+    if sigma_raw is None:
+        upd = floor.copy()
+    else:
+        upd = np.maximum(np.asarray(sigma_raw, dtype=float), floor)
+    upd[True ^ np.isfinite(upd)] = np.inf
+    return upd
+
+
+def rebin_edges(x, n_bin):
+    """Bin edges of DataObj._reBin (dataobj/dataobj.py:312-316): log-spaced, last point included."""
+    x = np.asarray(x, dtype=float)
+    return np.logspace(np.log10(x.min()), np.log10(x.max() + np.diff(x)[-1] / 100.), n_bin + 1)
+
+
+def rebin(x, f, fu, n_bin):
+    """DataObj._reBin (dataobj/dataobj.py:288-345) on the sanitized vectors: per bin the mean of x and f,
+    the larger of the standard error of the mean and the propagated uncertainty; empty bins dropped.
+    Returns (x_binned, f_binned, fu_binned)."""
+    x, f, fu = (np.asarray(a, dtype=float) for a in (x, f, fu))
+    edges = rebin_edges(x, n_bin)
+    xb = np.full(n_bin, np.nan); fb = np.full(n_bin, np.nan); ub = np.full(n_bin, np.nan)
+    valid = np.zeros(n_bin, dtype=bool)
+    for b in range(n_bin):
+        m = (x >= edges[b]) & (x < edges[b + 1])
+        cnt = int(m.sum())
+        if cnt == 1:
+            fb[b], ub[b], xb[b] = f[m][0], fu[m][0], x[m][0]
+            valid[b] = True
+        elif cnt > 1:
+            fb[b], xb[b] = f[m].mean(), x[m].mean()
+            valid[b] = True
+            ub[b] = max(f[m].std(ddof=1) / np.sqrt(1. * cnt), np.sqrt((fu[m] ** 2).sum() / cnt))
+    keep = (True ^ np.isnan(fb)) & valid
+    return xb[keep], fb[keep], ub[keep]

@@ -233,3 +233,18 @@ def test_g7_smeared_trajectory(method):
     np.testing.assert_allclose(res.rset, g["res_rset"], rtol=1e-15)
     np.testing.assert_allclose(res.conval, float(g["res_conval"]), rtol=1e-12 if method == "leastsq" else 1e-9)
     np.testing.assert_allclose(res.fit, g["res_fit"], rtol=1e-6)
+
+
+# ----------------------------------------------------------------------------- G8: input preparation
+@pytest.mark.parametrize("tag", ["demo", "dense"])
+def test_g8_uncertainty_floor_and_rebin(tag):
+    """DataObj._prepareUncertainty and DataObj._reBin (dataobj/dataobj.py:204-227, 288-345)."""
+    g = load("g8_input_prep.npz")
+    fu = O.prepare_uncertainty(g[tag + "_raw_f"], g[tag + "_raw_fu"], float(g[tag + "_fu_min"]))
+    np.testing.assert_array_equal(fu, g[tag + "_si_fu"])
+    xb, fb, ub = O.rebin(g[tag + "_san_x"], g[tag + "_san_f"], g[tag + "_san_fu"], int(g[tag + "_nbin"]))
+    np.testing.assert_array_equal(xb, g[tag + "_bin_x"])
+    np.testing.assert_array_equal(fb, g[tag + "_bin_f"])
+    np.testing.assert_array_equal(ub, g[tag + "_bin_fu"])
+    no_col = O.prepare_uncertainty(g[tag + "_raw_f"], None, 0.05)
+    np.testing.assert_array_equal(no_col, 0.05 * g[tag + "_raw_f"])

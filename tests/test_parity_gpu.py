@@ -450,3 +450,53 @@ def test_mcsas_mirror_with_smearing_matches_oracle():
     np.testing.assert_allclose(algo.fractions["vol"][0], fr["vol"][0], rtol=1e-6)
     np.testing.assert_allclose(algo.fractions["vol"][1], fr["vol"][1], rtol=1e-6)
     assert np.isfinite(h.bins.mean).all() and np.isfinite(h.observability).all()
+
+
+# ----------------------------------------------------------------------------- input preparation (§8 f4)
+@pytest.mark.parametrize("tag", ["demo", "dense"])
+def test_uncertainty_floor_and_rebin_vs_reference(tag):
+    """mcsas_hip_prepare_uncertainty / mcsas_hip_rebin against the reference's DataObj._prepareUncertainty /
+    _reBin outputs.  Bin membership, single-point bins and the floor are exact; means and standard errors
+    are sums in a different order than numpy's pairwise ones: 1e-13."""
+    g = load("g8_input_prep.npz")
+    fu = engine.prepare_uncertainty(g[tag + "_raw_f"], g[tag + "_raw_fu"], float(g[tag + "_fu_min"]))
+    np.testing.assert_array_equal(fu, g[tag + "_si_fu"])
+    np.testing.assert_array_equal(engine.prepare_uncertainty(g[tag + "_raw_f"], None, 0.05), 0.05 * g[tag + "_raw_f"])
+    xb, fb, ub = engine.rebin(g[tag + "_san_x"], g[tag + "_san_f"], g[tag + "_san_fu"], int(g[tag + "_nbin"]))
+    assert len(xb) == len(g[tag + "_bin_x"])
+    np.testing.assert_allclose(xb, g[tag + "_bin_x"], rtol=1e-13)
+    np.testing.assert_allclose(fb, g[tag + "_bin_f"], rtol=1e-13)
+    fin = np.isfinite(g[tag + "_bin_fu"])
+    np.testing.assert_array_equal(np.isfinite(ub), fin)
+    np.testing.assert_allclose(ub[fin], g[tag + "_bin_fu"][fin], rtol=1e-12)
+    single = np.array([np.sum((g[tag + "_san_x"] == v)) == 1 for v in xb])      # bins of one point are copies
+    np.testing.assert_array_equal(xb[single], g[tag + "_bin_x"][single])
+
+
+def test_fromraw_and_series_driver():
+    """SASData.fromRaw (floor + mask + rebin on the GPU) feeding McSAS through run_series: every data set of
+    the series gets its own result and one entry per histogram in the series table (gui/calc.py:331-349)."""
+    g = load("g8_input_prep.npz")
+    d = mcsas_amd.SASData.fromRaw(g["dense_san_x"], g["dense_san_f"], g["dense_san_fu"], nBin=60, fuMin=0.0)
+    np.testing.assert_allclose(d.q, g["dense_bin_x"], rtol=1e-13)
+    np.testing.assert_allclose(d.f.binnedData, g["dense_bin_f"], rtol=1e-13)
+    assert d.f.limit == [float(g["dense_san_f"].min()), float(g["dense_san_f"].max())]
+    q = np.logspace(7.3, 9.2, 300)
+    datasets = []
+    for radius in (1.0e-8, 2.5e-8):
+        _, spec = make_models("sphere", [1e-10], [1e-6])
+        I = O.calc_intensity(spec, q, [radius], 0.6666666)[0] * 1e20 + 1e-3
+        datasets.append(mcsas_amd.SASData.fromRaw(q, I, None, nBin=50, fuMin=0.02))
+    assert datasets[0].count <= 50 and np.allclose(datasets[0].f.binnedDataU / datasets[0].f.binnedData, 0.02, rtol=0.5)
+    m = mcsas_amd.Sphere(); m.radius.setActiveRange((2e-9, 1e-7))
+    m.radius.histograms().append(mcsas_amd.Histogram(m.radius, 2e-9, 1e-7, binCount=12, xscale='log', yweight='vol'))
+    algo = mcsas_amd.McSAS(seed=5)
+    algo.numContribs.setValue(60); algo.numReps.setValue(4); algo.maxIterations.setValue(4000)
+    algo.convergenceCriterion.setValue(50.0); algo.showIncomplete.setValue(True)
+    algo.model = m
+    results, series = mcsas_amd.run_series(algo, datasets, keys=[10.0, 25.0])
+    assert len(results) == 2 and all(r is not None for r in results)
+    (uid, rows), = series.items()
+    assert uid == ("radius", 2e-9, 1e-7, "vol") and [k for k, _ in rows] == [10.0, 25.0]
+    means = [fields[2] for _, fields in rows]                 # Moments.fields: (total, totalStd, mean, ...)
+    assert means[0] < means[1]                               # the larger spheres give the larger mean radius
