@@ -190,6 +190,16 @@ int mcsas_hip_bgfit(int32_t nq, const double *intensity, const double *sigma, co
 int mcsas_hip_observability(const mcsas_problem *problem, const double *contribs,
                             const double *scaling, const double *vol_frac, double *min_req_vol);
 
+/* ---- McSAS.histogram(), first half, for ALL repetitions in one call (mcsas.py:549-594) ----------
+ * Per rep: model.calc over its contributions (:552), scale/background fit of the summed intensity to
+ * the data (:559), per-contribution visibility limits min_q sigma*vf_c / (A*I_c(q)) (:575-590) with
+ * vf_c = wset_c * A / vset_c (modeldata.py:57-61).  Uses problem->{model, nq, q, intensity, sigma,
+ * n_contrib, n_reps, comp_exp, find_background, positive_background, smear_*, device}; contribs in the
+ * (n_contrib, n_active, n_reps) layout of mcsas_result.  scaling[2][n_reps] = (A, b) per rep;
+ * vset/wset/sset/min_req_vol [n_contrib][n_reps]. */
+int mcsas_hip_histogram_prep(const mcsas_problem *problem, const double *contribs, double *scaling,
+                             double *vset, double *wset, double *sset, double *min_req_vol);
+
 /* ---- input preparation ----------------------------------------------------------
  * DataObj._prepareUncertainty (dataobj/dataobj.py:204-227): sigma_out = max(sigma_raw, fu_min * I),
  * fu_min * I when sigma_raw is NULL (no uncertainty column), +inf where that is not finite. */

@@ -120,6 +120,69 @@ __global__ __launch_bounds__(64) void observability_kernel(ModelArgs m, int nq, 
     if (threadIdx.x == 0) min_req[(size_t)c * R + r] = best;
 }
 
+// ------------------------------------------------------------------------------ histogram(), batched
+// rows[r][c][q] = calcIntensity of contribution c of rep r, plus its v/w/s; one wave per (c, r)
+template <int M>
+__global__ __launch_bounds__(64) void hist_rows_kernel(ModelArgs m, int nq, const double *q, int N, int R, int r0,
+                                                       const double *contribs, double *rows, double *vset, double *wset,
+                                                       double *sset) {
+    extern __shared__ double tab[];
+    Contrib<M>::fill_table(m, tab, threadIdx.x, WAVE);
+    __syncthreads();
+    const int c = blockIdx.x, rl = blockIdx.y, r = r0 + rl, P = m.n_active;
+    double row[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+    for (int p = 0; p < P; ++p) row[p] = contribs[((size_t)c * P + p) * R + r];
+    Contrib<M> cc;
+    cc.prepare(m, row);
+    if (threadIdx.x == 0) { vset[(size_t)c * R + r] = cc.v; wset[(size_t)c * R + r] = cc.w; sset[(size_t)c * R + r] = cc.s; }
+    double *out = rows + ((size_t)rl * N + c) * nq;
+    for (int k = threadIdx.x; k < nq; k += WAVE) {
+        double it;
+        if (model_can_smear(M) && m.smear_nk > 0) it = smeared_intensity<M>(cc, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
+        else it = cc.intensity(q[k], tab);
+        out[k] = it;
+    }
+}
+
+// per rep: cumInt = sum of its rows in contribution order (scatteringmodel.py:101), then the closed-form
+// scale/background fit (mcsas.py:559); one wave per rep
+__global__ __launch_bounds__(64) void hist_fit_kernel(int nq, const double *I, const double *sigma, int N, int R, int r0,
+                                                      const double *rows, int find_bg, int pos_bg, double *scaling) {
+    const int rl = blockIdx.x, r = r0 + rl, lane = threadIdx.x;
+    const double *base = rows + (size_t)rl * N * nq;
+    double sw = 0, si = 0, sii = 0, sc = 0, scc = 0, sic = 0;
+    for (int k = lane; k < nq; k += WAVE) {
+        double C = 0.;
+        for (int n = 0; n < N; ++n) C += base[(size_t)n * nq + k];
+        const double e = sigma[k] == 0.0 ? 1.0 : sigma[k];
+        const double w = 1.0 / (e * e);
+        sw += w; si += w * I[k]; sii += w * I[k] * I[k];
+        sc += w * C; scc += w * C * C; sic += w * I[k] * C;
+    }
+    wave_sum3(sw, si, sii); wave_sum3(sc, scc, sic);
+    ChainArgs a{};
+    a.Sw = sw; a.SI = si; a.SII = sii; a.nq = nq; a.find_bg = find_bg; a.pos_bg = pos_bg;
+    const FitResult f = solve_fit(a, sc, scc, sic);
+    if (lane == 0) { scaling[r] = f.A; scaling[R + r] = f.b; }
+}
+
+// min over q of sigma*vf / (A*I_c(q)), I_c != 0 (mcsas.py:582-590) from the stored rows
+__global__ __launch_bounds__(64) void hist_obs_kernel(int nq, const double *sigma, int N, int R, int r0, const double *rows,
+                                                      const double *scaling, const double *vset, const double *wset,
+                                                      double *min_req) {
+    const int c = blockIdx.x, rl = blockIdx.y, r = r0 + rl;
+    const double A = scaling[r];
+    const double vf = wset[(size_t)c * R + r] * A / vset[(size_t)c * R + r];      // modeldata.py:57-61
+    const double *row = rows + ((size_t)rl * N + c) * nq;
+    double best = INFINITY;
+    for (int k = threadIdx.x; k < nq; k += WAVE) {
+        const double scaled = A * row[k];
+        if (scaled != 0.) best = fmin(best, (sigma[k] * vf) / scaled);
+    }
+    best = wave_min(best);
+    if (threadIdx.x == 0) min_req[(size_t)c * R + r] = best;
+}
+
 // ------------------------------------------------------------------------------ input preparation
 // DataObj._prepareUncertainty (dataobj/dataobj.py:204-227)
 __global__ void prepare_uncertainty_kernel(int n, const double *I, const double *su, double fu_min, double *out) {
@@ -780,6 +843,55 @@ extern "C" int mcsas_hip_observability(const mcsas_problem *p, const double *con
         default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
     }
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(min_req_vol, dm.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_histogram_prep(const mcsas_problem *p, const double *contribs, double *scaling, double *vset,
+                                        double *wset, double *sset, double *min_req_vol) {
+    if (!p || !contribs || !scaling || !vset || !wset || !sset || !min_req_vol || !p->q || !p->intensity || !p->sigma ||
+        p->nq < 1 || p->n_contrib < 1 || p->n_reps < 1)
+        return fail(MCSAS_EINVAL, "bad argument");
+    ModelArgs m;
+    int rc = fill_model_args(p, &m);
+    if (rc) return rc;
+    rc = select_device(p->device);
+    if (rc) return rc;
+    const size_t Q = p->nq, P = p->n_active, N = p->n_contrib, R = p->n_reps;
+    // the rows of a block of repetitions stay in HBM between the three kernels; blocks of at most ~8 GB
+    const size_t per_rep = N * Q * sizeof(double);
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(R, ((size_t)8 << 30) / per_rep));
+    DevBuf<double> dq, dI, dsg, dc, drows, dsc, dv, dw, ds, dm;
+    HIPCHK(dq.alloc(Q)); HIPCHK(dI.alloc(Q)); HIPCHK(dsg.alloc(Q)); HIPCHK(dc.alloc(N * P * R)); HIPCHK(drows.alloc(chunk * N * Q));
+    HIPCHK(dsc.alloc(2 * R)); HIPCHK(dv.alloc(N * R)); HIPCHK(dw.alloc(N * R)); HIPCHK(ds.alloc(N * R)); HIPCHK(dm.alloc(N * R));
+    HIPCHK(hipMemcpy(dq.p, p->q, sizeof(double) * Q, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dI.p, p->intensity, sizeof(double) * Q, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dsg.p, p->sigma, sizeof(double) * Q, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dc.p, contribs, sizeof(double) * N * P * R, hipMemcpyHostToDevice));
+    SmearDev smear;
+    rc = smear.upload(p, p->nq, &m);
+    if (rc) return rc;
+    const size_t lds = sizeof(double) * table_doubles_host(p->model_id, m.int_div);
+    for (size_t r0 = 0; r0 < R; r0 += chunk) {
+        const unsigned nr = (unsigned)std::min(chunk, R - r0);
+        const dim3 grid((unsigned)N, nr);
+        switch (p->model_id) {
+#define CASE_K(mm) case mm: hist_rows_kernel<mm><<<grid, WAVE, lds>>>(m, p->nq, dq.p, (int)N, (int)R, (int)r0, dc.p, drows.p, dv.p, dw.p, ds.p); break;
+            MCSAS_FOR_MODELS(CASE_K)
+#undef CASE_K
+            default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
+        }
+        HIPCHK(hipGetLastError());
+        hist_fit_kernel<<<nr, WAVE>>>(p->nq, dI.p, dsg.p, (int)N, (int)R, (int)r0, drows.p, p->find_background != 0,
+                                      p->positive_background != 0, dsc.p);
+        HIPCHK(hipGetLastError());
+        hist_obs_kernel<<<grid, WAVE>>>(p->nq, dsg.p, (int)N, (int)R, (int)r0, drows.p, dsc.p, dv.p, dw.p, dm.p);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpy(scaling, dsc.p, sizeof(double) * 2 * R, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(vset, dv.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(wset, dw.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sset, ds.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(min_req_vol, dm.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
     return MCSAS_OK;
 }

@@ -255,6 +255,21 @@ def observability(model: ModelSetup, q, sigma, contribs, scaling, vol_frac, comp
     return out
 
 
+def histogram_prep(model: ModelSetup, q, intensity, sigma, contribs, comp_exp, find_background=True,
+                   positive_background=False, device=-1, smear=None):
+    """First half of McSAS.histogram() (mcsas.py:549-594) for all repetitions in one call: returns
+    scaling[2][R] (scale, background per rep), vset, wset, sset and the visibility limits, each [N][R]."""
+    lib = _lib.load()
+    contribs = f64(contribs)
+    N, P, R = contribs.shape
+    st = Settings(n_contrib=N, n_reps=R, comp_exp=comp_exp, device=device, find_background=find_background,
+                  positive_background=positive_background)
+    prob = HipProblem(model, q, intensity, sigma, st, smear=smear)
+    sc = np.zeros((2, R)); v = np.zeros((N, R)); w = np.zeros((N, R)); s = np.zeros((N, R)); mv = np.zeros((N, R))
+    check(lib.mcsas_hip_histogram_prep(C.byref(prob.c), as_dp(contribs), as_dp(sc), as_dp(v), as_dp(w), as_dp(s), as_dp(mv)))
+    return sc, v, w, s, mv
+
+
 def prepare_uncertainty(intensity, sigma_raw, fu_min, device=-1):
     """DataObj._prepareUncertainty (dataobj/dataobj.py:204-227) on the GPU."""
     lib = _lib.load()

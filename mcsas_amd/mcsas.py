@@ -152,33 +152,24 @@ class McSAS(object):
         setup = setup_from_model(model, data)
         smear = data.smearArgs(model) if hasattr(data, "smearArgs") else None
         c = self.compensationExponent()
-        vf = np.zeros((numContribs, numReps)); nf = np.zeros_like(vf); qf = np.zeros_like(vf); sf = np.zeros_like(vf)
-        vsets = np.zeros_like(vf); ssets = np.zeros_like(vf)
-        scalingFactors = np.zeros((2, numReps))
-        for ri in range(numReps):
-            cum, vset, wset, sset = engine.model_calc(setup, data.q, contribs[:, :, ri], c, device=self.device, smear=smear)   # :552
-            sc, conval, _ = engine.bgfit(data.f.binnedData, data.f.binnedDataU, cum, self.findBackground.value(),
-                                         self.positiveBackground.value(), setup.n_active, device=self.device)      # :559
-            scalingFactors[:, ri] = sc
-            vf[:, ri] = wset * sc[0] / vset                  # modeldata.py:57-61
-            nf[:, ri] = vf[:, ri] / vset
-            qf[:, ri] = vf[:, ri] * vset
-            sf[:, ri] = nf[:, ri] * sset
-            vsets[:, ri], ssets[:, ri] = vset, sset
-        # observability: N single-row model evaluations per rep (:575-590), one launch for all
+        # model.calc, the scale/background fit and the N single-row visibility limits of every repetition
+        # (:552, :559, :575-590): one library call for all of them
         sig = np.array(data.f.binnedDataU, dtype=float)
-        mv = engine.observability(setup, data.q, sig, contribs, scalingFactors[0], vf, c, device=self.device, smear=smear)
+        scalingFactors, vsets, wsets, ssets, mv = engine.histogram_prep(
+            setup, data.q, data.f.binnedData, sig, contribs, c, self.findBackground.value(),
+            self.positiveBackground.value(), device=self.device, smear=smear)
+        vf = wsets * scalingFactors[0][None, :] / vsets          # modeldata.py:57-61
+        nf = vf / vsets
+        qf = vf * vsets
+        sf = nf * ssets
         mn = mv / vsets                                      # :591-594
         mq = mn * mv * mv
         ms = mn * ssets
-        for ri in range(numReps):                            # :596-604
-            tn, tq, ts = sum(nf[:, ri]), sum(qf[:, ri]), sum(sf[:, ri])
-            if 0 != tn:
-                nf[:, ri] /= tn; mn[:, ri] /= tn
-            if 0 != tq:
-                qf[:, ri] /= tq; mq[:, ri] /= tq
-            if 0 != ts:
-                sf[:, ri] /= ts; ms[:, ri] /= ts
+        # normalisation per repetition (:596-604); cumsum adds in the order of the reference's builtin sum()
+        for frac, lim in ((nf, mn), (qf, mq), (sf, ms)):
+            tot = np.cumsum(frac, axis=0)[-1]
+            nz = tot != 0
+            frac[:, nz] /= tot[nz]; lim[:, nz] /= tot[nz]
         fractions = dict(vol=(vf, mv), num=(nf, mn), int=(qf, mq), surf=(sf, ms))
         self.result[0]['scalingFactors'] = scalingFactors
         self.fractions = fractions

@@ -228,16 +228,18 @@ class Moments(object):
             if not valid.any():
                 continue
             rset, frac = vals[valid, ri], fraction[valid, ri]
-            val[ri] = sum(frac)
-            mu[ri] = sum(rset * frac)
-            if 0 != sum(frac):
-                mu[ri] /= sum(frac)
-            var[ri] = sum((rset - mu[ri])**2 * frac) / sum(frac)
+            ssum = lambda x: np.cumsum(x)[-1]                 # adds in the order of the reference's builtin sum()
+            tot = ssum(frac)
+            val[ri] = tot
+            mu[ri] = ssum(rset * frac)
+            if 0 != tot:
+                mu[ri] /= tot
+            var[ri] = ssum((rset - mu[ri])**2 * frac) / tot
             sigma = np.sqrt(abs(var[ri]))
-            if (sum(frac) * sigma) == 0.0:
+            if (tot * sigma) == 0.0:
                 continue
-            skw[ri] = sum((rset - mu[ri])**3 * frac) / (sum(frac) * sigma**3)
-            krt[ri] = sum((rset - mu[ri])**4 * frac) / (sum(frac) * sigma**4)
+            skw[ri] = ssum((rset - mu[ri])**3 * frac) / (tot * sigma**3)
+            krt[ri] = ssum((rset - mu[ri])**4 * frac) / (tot * sigma**4)
         ddof = 1 if numReps > 1 else 0
         self.total = (val.mean(), val.std(ddof=ddof)); self.mean = (mu.mean(), mu.std(ddof=ddof))
         self.variance = (var.mean(), var.std(ddof=ddof)); self.skew = (skw.mean(), skw.std(ddof=ddof))
@@ -322,25 +324,29 @@ class Histogram(object):
         self._setXLowerEdge()
         numContribs, dummy, numReps = contribs.shape
         frac, minReq = fractions[self.yweight]
-        binLst, obsLst, cdfLst = [], [], []
-        for ri in range(numReps):
-            parValues = contribs[:, paramIndex, ri]
-            bins = np.zeros(self.binCount); binObs = np.zeros(self.binCount)
-            for bi in range(self.binCount):                   # _calcBins/_calcBin :441-469
-                mask = (parValues >= self.xLowerEdge[bi]) * (parValues < self.xLowerEdge[bi + 1])
-                v = sum(frac[mask, ri])
-                bins[bi] = 0. if np.isnan(v) else v
-                binObs[bi] = minReq[mask, ri].mean() if mask.any() else 0.
-            cdf = np.cumsum(bins)                             # _calcCDF :471-479
-            cdf = np.zeros_like(bins) if cdf.max() == 0.0 else cdf / cdf.max()
-            binLst.append(bins); obsLst.append(binObs); cdfLst.append(cdf)
-        self.bins = VectorResult(np.vstack(binLst).T)
-        self.cdf = VectorResult(np.vstack(cdfLst).T)
-        allObs = np.vstack(obsLst).T
-        self.observability = np.zeros(self.binCount)          # _setObservability :390-402
-        for bi in range(self.binCount):
-            obs = allObs[bi, :]
-            obs = obs[obs < np.inf]
-            if len(obs):
-                self.observability[bi] = obs.max()
+        # _calcBins/_calcBin (:441-469) for every (bin, repetition) at once.  A contribution with
+        # edge[b] <= x < edge[b+1] belongs to bin b; numpy.add.at accumulates unbuffered and in index order,
+        # i.e. in the order of the reference's builtin sum() over the masked contributions.
+        nb = self.binCount
+        par = contribs[:, paramIndex, :]
+        b = np.searchsorted(self.xLowerEdge, par, side='right') - 1
+        inb = (b >= 0) & (b < nb) & (par < self.xLowerEdge[-1])
+        rr = np.broadcast_to(np.arange(numReps)[None, :], par.shape)
+        idx = (b[inb], rr[inb])
+        bins = np.zeros((nb, numReps)); obsSum = np.zeros((nb, numReps)); cnt = np.zeros((nb, numReps))
+        np.add.at(bins, idx, frac[inb])
+        np.add.at(obsSum, idx, minReq[inb])
+        np.add.at(cnt, idx, 1.)
+        bins[np.isnan(bins)] = 0.
+        with np.errstate(invalid='ignore', divide='ignore'):
+            allObs = np.where(cnt > 0, obsSum / cnt, 0.)      # mean of the members' visibility limits
+        cdf = np.cumsum(bins, axis=0)                         # _calcCDF :471-479
+        top = cdf.max(axis=0) if nb else np.zeros(numReps)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            cdf = np.where(top[None, :] == 0.0, 0., cdf / top[None, :])
+        self.bins = VectorResult(bins)
+        self.cdf = VectorResult(cdf)
+        finite = np.where(allObs < np.inf, allObs, -np.inf)   # _setObservability :390-402
+        best = finite.max(axis=1) if numReps else np.zeros(nb)
+        self.observability = np.where(np.isfinite(best), best, 0.)
         self.moments = Moments(contribs, paramIndex, self.xrange, frac)

@@ -143,3 +143,27 @@ def test_smearing_value_ranges_follow_the_data():
     sm.umbra.setValue(6e7)
     sm.penumbra.setValue(1e7)
     assert sm.penumbra() == 6e7 and not sm.inputValid()
+
+
+def test_histogram_host_binning_matches_reference(golden_dir):
+    """mcsas_amd.Histogram.calc / Moments (the vectorised host half of McSAS.histogram(), utils/parameter.py:
+    20-122, 349-479) on fractions from the oracle, against the reference's bins, CDF, observability and
+    moments (fixture G5)."""
+    from oracle import mcsas_oracle as O
+    from helpers import make_models
+    g = np.load(os.path.join(golden_dir, "g45_analyse.npz"))
+    lo, hi = float(g["A_lo"]), float(g["A_hi"])
+    m, spec = make_models("sphere", [lo], [hi])
+    st = O.Settings(n_contrib=150, n_reps=3, max_iter=100000, conv_crit=5.0)
+    frac, _ = O.fractions(spec, g["data_q"], g["data_I"], g["data_sigma"], g["data_f_limit"], st, g["A_contribs"], method="leastsq")
+    for hi_, (bc, xlog, yw) in enumerate(g["A_h_spec"]):
+        h = mcsas_amd.Histogram(m.radius, lo, hi, binCount=int(bc), xscale="log" if xlog else "lin", yweight=O.YWEIGHTS[int(yw)])
+        h.calc(g["A_contribs"], 0, frac)
+        p = "A_h%d_" % hi_
+        np.testing.assert_allclose(h.xLowerEdge, g[p + "edges"], rtol=1e-15)
+        np.testing.assert_allclose(h.bins.full, g[p + "bins_full"], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(h.bins.mean, g[p + "bins_mean"], rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(h.bins.std, g[p + "bins_std"], rtol=1e-8, atol=1e-300)
+        np.testing.assert_allclose(h.cdf.mean, g[p + "cdf_mean"], rtol=1e-9)
+        np.testing.assert_allclose(h.observability, g[p + "obs"], rtol=1e-9)
+        np.testing.assert_allclose(np.array(h.moments.fields)[0::2], g[p + "moments"][0::2], rtol=1e-9)

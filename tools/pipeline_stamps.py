@@ -15,7 +15,9 @@ from bench import synthetic_data
 q, I, sig = synthetic_data(512)
 m = mcsas_amd.Sphere()
 m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
-st = engine.Settings(n_contrib=400, n_reps=50, max_iter=20000, conv_crit=0.0, max_retries=0, seed=2, exec_mode=0)
+import os
+st = engine.Settings(n_contrib=400, n_reps=50, max_iter=20000, conv_crit=0.0, max_retries=0, seed=2, exec_mode=0,
+                     debug_flags=int(os.environ.get("MCSAS_DEBUG_FLAGS", "0")))
 plan = engine.Plan(m.setup(), q, I, sig, st)
 plan.launch(); res = plan.fetch()
 print("ms", plan.last_ms, "moves mean", res.num_moves.mean(), "iters", res.num_iter.mean(), plan.info)

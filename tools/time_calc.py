@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Wall time of McSAS.calc() end to end (analyse + histogram) on BASELINE config 2's shape."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import mcsas_amd
+from bench import synthetic_data
+
+q, I, sig = synthetic_data(512)
+d = mcsas_amd.SASData(q, I, sig)
+m = mcsas_amd.Sphere(); m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
+m.radius.histograms().append(mcsas_amd.Histogram(m.radius, np.pi / q.max(), np.pi / q.min(), binCount=50, xscale='log', yweight='vol'))
+algo = mcsas_amd.McSAS(seed=1)
+algo.numContribs.setValue(400); algo.numReps.setValue(50); algo.convergenceCriterion.setValue(2.0)
+algo.model, algo.data = m, d
+for it in range(3):
+    algo.result = []
+    t0 = time.perf_counter(); algo.analyse(); t1 = time.perf_counter(); algo.histogram(); t2 = time.perf_counter()
+    print("run %d: analyse %.1f ms, histogram %.1f ms, chisq max %.3f" % (it, (t1 - t0) * 1e3, (t2 - t1) * 1e3, algo.details.chisq.max()))
+
+# where histogram() spends its time
+from mcsas_amd import engine
+from mcsas_amd.scatteringmodels import setup_from_model
+contribs = algo.result[0]['contribs']
+setup = setup_from_model(m, d)
+for it in range(2):
+    t0 = time.perf_counter()
+    out = engine.histogram_prep(setup, d.q, d.f.binnedData, d.f.binnedDataU, contribs, 0.6666666)
+    t1 = time.perf_counter()
+    for paramIndex, param in enumerate(m.activeParams()):
+        param.histograms().calc(contribs, paramIndex, algo.fractions)
+    t2 = time.perf_counter()
+    print("histogram_prep %.1f ms, Histogram.calc (host binning) %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
