@@ -31,3 +31,15 @@ for it in range(2):
         param.histograms().calc(contribs, paramIndex, algo.fractions)
     t2 = time.perf_counter()
     print("histogram_prep %.1f ms, Histogram.calc (host binning) %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+
+# where analyse() spends its time
+st = engine.Settings(n_contrib=400, n_reps=50, max_iter=100000, conv_crit=2.0, max_retries=5, seed=1)
+for it in range(3):
+    t0 = time.perf_counter()
+    plan = engine.Plan(setup, d.q, d.f.binnedData, d.f.binnedDataU, st)
+    t1 = time.perf_counter()
+    plan.launch(); res = plan.fetch()
+    t2 = time.perf_counter()
+    plan.close()
+    t3 = time.perf_counter()
+    print("plan create %.2f ms, launch+fetch %.2f ms (device %.2f ms), destroy %.2f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, plan.last_ms if False else 0.0, (t3 - t2) * 1e3))
