@@ -350,6 +350,31 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
         o.ratio = readlane_f64(ratio, lane); o.w = readlane_f64(w, lane); o.v = 0.; o.s = 0.;
         return o;
     }
+    // cD phi1(t) - D2x phi2(t), phi1(t) = (1 - exp(-t))/t, phi2(t) = (1 - (1+t) exp(-t))/t² (series below t = 0.5)
+    static __device__ __forceinline__ double kho_tail(double t, double cD, double D2x) {
+        const double em1 = -expm1(-t);                         // 1 - exp(-t)
+        const double p1 = em1 / t;
+        double p2;
+        if (t < 0.5) {                                         // sum_k (-1)^k (k+1)/(k+2)! t^k
+            p2 = -1.07060292245477428e-11;                      // k = 13
+            p2 = fma(p2, t, 1.49119692770486430e-10);
+            p2 = fma(p2, t, -1.92708526041859370e-09);
+            p2 = fma(p2, t, 2.29644326866549102e-08);
+            p2 = fma(p2, t, -2.50521083854417176e-07);
+            p2 = fma(p2, t, 2.48015873015873016e-06);
+            p2 = fma(p2, t, -2.20458553791887140e-05);
+            p2 = fma(p2, t, 1.73611111111111118e-04);
+            p2 = fma(p2, t, -1.19047619047619058e-03);
+            p2 = fma(p2, t, 6.94444444444444406e-03);
+            p2 = fma(p2, t, -3.33333333333333329e-02);
+            p2 = fma(p2, t, 1.25000000000000000e-01);
+            p2 = fma(p2, t, -3.33333333333333315e-01);
+            p2 = fma(p2, t, 5.00000000000000000e-01);
+        } else {
+            p2 = (em1 - t * (1.0 - em1)) / (t * t);
+        }
+        return cD * p1 - D2x * p2;
+    }
     __device__ __forceinline__ double intensity(double q, const double *tab) const {
         const double invx = 1.0 / x;
         double acc = 0.;
@@ -404,9 +429,16 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
             const double e2 = 1.0 - q * q * lk * lk / 9.;
             const double e = (q < ratio && e2 > 0.) ? sqrt(e2) : 0.;
             const double a1 = 1.0 - e;
+            // away from e = 0 the range beyond z0 = 2 is integrated in closed form like the oscillatory branch:
+            //   sinh(e z)/(e sinh z) = (1/e) sum_m [exp(-(a-e) z) - exp(-(a+e) z)],  a = 2m+1,
+            //   int_{z0}^{x} exp(-b z)(1 - z/x) dz = exp(-b z0) [ (1 - z0/x) D phi1(b D) - D²/x phi2(b D) ],  D = x - z0,
+            //   phi1(t) = (1 - exp(-t))/t,  phi2(t) = (1 - (1+t) exp(-t))/t²   (no cancellation for small b D);
+            // checked against QUADPACK at 1e-13: 3e-15.  Near e = 0 the difference quotient cancels: panels.
+            const bool closed = e >= 0.05;
+            const double zsplit = closed ? fmin(x, 2.0) : x;
             double left = 0., width = 1.0;
-            while (left < x) {
-                const double right = fmin(x, left + width);
+            while (left < zsplit) {
+                const double right = fmin(zsplit, left + width);
                 const double hw = 0.5 * (right - left), mid = 0.5 * (right + left);
                 double pa = 0.;
 #pragma unroll 4
@@ -422,6 +454,18 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
                 left = right;
                 if (left >= 2.0) width = left;
                 if (a1 * left > 42.0) break;
+            }
+            if (closed && x > zsplit) {
+                const double z0 = zsplit, D = x - z0, cD = (1.0 - z0 * invx) * D, D2x = D * D * invx;
+                const double r0 = exp(-2. * z0), ep = exp(e * z0), en = 1.0 / ep;
+                double ea = exp(-z0), tail = 0.;
+#pragma unroll 1
+                for (int m = 0; m < 11; ++m) {
+                    const double a = (double)(2 * m + 1);
+                    tail += ea * (ep * kho_tail(( a - e) * D, cD, D2x) - en * kho_tail((a + e) * D, cD, D2x));
+                    ea *= r0;
+                }
+                acc += tail / e;
             }
         }
         const double p0 = sqrt(acc * (2.0 * invx));                      // coreIntegral (:32-37)

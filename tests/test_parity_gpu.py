@@ -500,3 +500,19 @@ def test_fromraw_and_series_driver():
     assert uid == ("radius", 2e-9, 1e-7, "vol") and [k for k, _ in rows] == [10.0, 25.0]
     means = [fields[2] for _, fields in rows]                 # Moments.fields: (total, totalStd, mean, ...)
     assert means[0] < means[1]                               # the larger spheres give the larger mean radius
+
+
+def test_kholodenko_regimes_vs_quadpack():
+    """The worm-like chain form factor across its regimes against the oracle's QUADPACK evaluation
+    (models/kholodenko.py:32-49, epsrel 1e-10): contour shorter than the closed-form split (x < 2), x of
+    a few hundred, q l_k/3 far below, around (panel fallback, |e| < 0.05) and far above 1."""
+    rs = np.random.RandomState(9)
+    m, spec = make_models("kholodenko", [1e-10, 1e-9, 1e-9], [1e-7, 1e-6, 1e-4])
+    for lk, lc in ((2e-8, 1e-8), (3e-8, 2.5e-8), (1e-8, 6e-8), (2e-8, 1.5e-6), (5e-8, 4e-7)):
+        ratio = 3.0 / lk
+        q = np.sort(np.concatenate([ratio * 10 ** rs.uniform(-2.5, 1.7, 24), ratio * (1 + rs.uniform(-2e-3, 2e-3, 6)),
+                                    [ratio, ratio * (1 - 1e-9), ratio * (1 + 1e-9)]]))
+        row = np.array([[2e-9, lk, lc]])
+        ref = O.calc_intensity(spec, q, row[0], 0.6666666)[0]
+        got = engine.model_calc(m.setup(), q, row, 0.6666666, want_rows=True)[4][0]
+        np.testing.assert_allclose(got, ref, rtol=2e-9)
