@@ -516,3 +516,52 @@ def test_kholodenko_regimes_vs_quadpack():
         ref = O.calc_intensity(spec, q, row[0], 0.6666666)[0]
         got = engine.model_calc(m.setup(), q, row, 0.6666666, want_rows=True)[4][0]
         np.testing.assert_allclose(got, ref, rtol=2e-9)
+
+
+RANDOM_RANGES = {   # generator ranges per model tag (SI)
+    "sphere": ([2e-9], [3e-7]), "cyl_aspect": ([1e-9, 0.5], [1e-7, 20.0]), "cyl_length": ([1e-9, 5e-9], [1e-7, 5e-7]),
+    "ellcs": ([1e-9, 2e-9, 2e-10], [1e-7, 2e-7, 1e-8]), "kholodenko": ([1e-9, 1e-8, 1e-7], [5e-9, 5e-8, 1e-6]),
+    "elliso": ([1e-9, 0.3], [1e-7, 8.0]), "sphcs": ([1e-9, 5e-10], [1e-7, 2e-8]), "gausschain": ([1e-9, 1e-9], [1e-7, 1e-7]),
+    "lmasphere": ([2e-9, 0.01], [2e-7, 0.4]),
+}
+
+
+@pytest.mark.parametrize("case", range(18))
+def test_random_configurations_all_modes_identical(case):
+    """Seeded sweep over model, q count, contribution count, repetitions, step budget, convergence criterion,
+    retries and the three fit flags: the execution modes that accept a configuration walk identical chains
+    (parameter sets, iteration / move / draw / attempt counts: exact); the chi², scale, background and fit
+    reported at the end are re-summed once per mode in its own lane order: 1e-12."""
+    rs = np.random.RandomState(1000 + case)
+    tag = list(RANDOM_RANGES)[case % len(RANDOM_RANGES)]
+    heavy = tag in ("cyl_aspect", "cyl_length", "ellcs", "kholodenko", "elliso")
+    nq = int(rs.choice([5, 33, 64, 100, 257] if heavy else [5, 33, 64, 100, 257, 512, 700]))
+    n = int(rs.choice([16, 24, 50, 130] if heavy else [16, 24, 50, 130, 300, 400]))
+    reps = int(rs.randint(1, 5))
+    steps = int(rs.randint(1, 4 * n))
+    lo, hi = RANDOM_RANGES[tag]
+    m, spec = make_models(tag, lo, hi)
+    q = np.sort(10 ** rs.uniform(7.2, 9.3, nq))
+    truth = np.array([10 ** rs.uniform(np.log10(a), np.log10(b), 12) for a, b in zip(lo, hi)]).T
+    I = O.model_calc(spec, q, truth, 0.6666666)[0]
+    I = I * (1 + 0.03 * rs.standard_normal(nq)) + 0.02 * I.mean()
+    sig = 0.03 * np.abs(I) + 1e-3 * np.abs(I).mean()
+    kw = dict(find_background=bool(rs.randint(2)), positive_background=bool(rs.randint(2)),
+              start_from_minimum=bool(rs.randint(4) == 0), max_retries=int(rs.randint(0, 3)),
+              conv_crit=float(rs.choice([1e-9, 5.0, 200.0])))
+    outs = []
+    for mode in (engine.EXEC_WAVE, engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE):
+        st = engine.Settings(n_contrib=n, n_reps=reps, max_iter=steps, seed=77 + case, exec_mode=mode, **kw)
+        try:
+            outs.append((mode, engine.analyse(m.setup(FakeData(q)), q, I, sig, st)))
+        except mcsas_amd._lib.McSASHipError as e:
+            assert e.code == -1 and mode != engine.EXEC_WAVE
+    assert len(outs) >= 2
+    ref = outs[0][1]
+    assert np.isfinite(ref.chisq).all() and (ref.num_iter <= steps).all()
+    for mode, res in outs[1:]:
+        for f in ("contribs", "num_iter", "num_moves", "attempts", "converged", "draws"):
+            np.testing.assert_array_equal(getattr(res, f), getattr(ref, f), err_msg="%s differs in mode %d (%s nq=%d n=%d)" % (f, mode, tag, nq, n))
+        for f in ("chisq", "scaling", "fit"):
+            np.testing.assert_allclose(getattr(res, f), getattr(ref, f), rtol=1e-12, err_msg="%s differs in mode %d (%s nq=%d n=%d)" % (f, mode, tag, nq, n))
+        np.testing.assert_allclose(res.background, ref.background, rtol=1e-9, atol=1e-12 * np.abs(I).max())
