@@ -237,7 +237,8 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
 template <int QPL>
 __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds, int rep, int t, int stop_now) {
     const ChainArgs &a = pa.c;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is wave-uniform: keep it (and the row bookkeeping that hangs on it) on the scalar unit
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb;
     const int NW = pa.g.scan_waves, T = NW * WAVE;
     PipeChain &ch = pa.chains[rep];
@@ -249,7 +250,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #endif
     const PipeSnap sn = ch.snap[(t + 1) & 1];                 // the record in force for tick t (written at t-1; host for t = 0)
 
-    const int RING = pa.g.ring;
+    const int RING = pa.g.ring, RMASK = RING - 1;             // ring depth is 4, 2 or 1
     double *ring = lds + (size_t)wave * RING * qpad;                       // this wave's RING rows
     double *ssub = lds + (size_t)NW * RING * qpad;                   // [Kb][4] scalars of the whole window
     double *hbuf = ssub + (size_t)Kb * 4;                                  // [8] h of the current group, by step offset
@@ -316,7 +317,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         const bool dma_lane = (QPL >= 2) || lane < 32;
         auto issue_row = [&](int m) {                          // m-th row of this wave: r = wave + 8 m
             const char *gsrc = reinterpret_cast<const char *>(dwin + (size_t)(wave + 8 * m) * qpad) + lane * 16;
-            double *ldst = ring + (size_t)(m % RING) * qpad;
+            double *ldst = ring + (size_t)(m & RMASK) * qpad;
             if (dma_lane) {
 #pragma unroll
                 for (int c = 0; c < CALLS; ++c)
@@ -408,8 +409,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CALLS) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 MCSAS_STAMP(s2);
-                const double *dr = ring + (size_t)(m0 % RING) * qpad + lane;
-                const double *dr1 = ring + (size_t)((m0 + 1) % RING) * qpad + lane;
+                const double *dr = ring + (size_t)(m0 & RMASK) * qpad + lane;
+                const double *dr1 = ring + (size_t)((m0 + 1) & RMASK) * qpad + lane;
                 double h0 = 0., h1 = 0., e0 = 0., e1 = 0.;
 #pragma unroll
                 for (int j = 0; j < QPL; j += 2) {
@@ -505,7 +506,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             if (acc_row >= 0) {
                 // ft += d, w ft refreshed (mcsas.py:381-382): the accepted row sits in its owner's ring,
                 // landed before B1 and not refilled before the next B1
-                const double *dr = lds + ((size_t)(acc_row & 7) * RING + (size_t)((acc_row >> 3) % RING)) * qpad;
+                const double *dr = lds + ((size_t)(acc_row & 7) * RING + (size_t)((acc_row >> 3) & RMASK)) * qpad;
                 double dv[QPL];
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) dv[j] = dr[lane + WAVE * j];
