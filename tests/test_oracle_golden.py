@@ -248,3 +248,48 @@ def test_g8_uncertainty_floor_and_rebin(tag):
     np.testing.assert_array_equal(ub, g[tag + "_bin_fu"])
     no_col = O.prepare_uncertainty(g[tag + "_raw_f"], None, 0.05)
     np.testing.assert_array_equal(no_col, 0.05 * g[tag + "_raw_f"])
+
+
+# ----------------------------------------------------------------------------- the C restatement (oracle/c)
+C_TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q512_fixed.npz",
+          "g4_sphere_q100_nobg.npz", "g4_sphere_q100_posbg.npz", "g4_sphere_q100_frommin.npz"]
+
+
+@pytest.mark.parametrize("name", C_TRAJ)
+def test_c_oracle_replays_reference_trajectories(name):
+    """oracle/c/mcsas_oracle.c (plain C, libm) on the uniform stream the reference consumed: the
+    reference's accept/reject sequence, parameter set, chi² and fit."""
+    from oracle import c_oracle
+    g, spec, st = traj_setup(name)
+    mb = min(spec.lo[0], spec.hi[0]); mb = mb if mb != 0 else np.pi / g["data_x0_limit"][1]
+    r = c_oracle.analyse_sphere(g["data_q"], g["data_I"], g["data_sigma"], spec.lo[0], spec.hi[0], st.n_contrib, 1,
+                                st.max_iter, st.conv_crit, comp_exp=st.comp_exp, find_bg=st.find_bg, pos_bg=st.pos_bg,
+                                start_from_min=st.start_from_min, start_value=0.5 * mb, replay=g["stream"][None, :],
+                                want_accepted=int(g["res_num_moves"]) + 4)
+    assert r.num_iter[0] == int(g["res_num_iter"]) and r.num_moves[0] == int(g["res_num_moves"])
+    np.testing.assert_array_equal(r.accepted[0, :r.num_moves[0]], g["res_accepted"])
+    np.testing.assert_allclose(r.contribs[:, 0, 0], g["res_rset"][:, 0], rtol=1e-15)
+    np.testing.assert_allclose(r.chisq[0], float(g["res_conval"]), rtol=1e-5 if "posbg" in name else 1e-9)
+    np.testing.assert_allclose(r.fit[:, 0], g["res_fit"], rtol=1e-6)
+
+
+def test_c_oracle_philox_and_threads_match_numpy_oracle():
+    from oracle import c_oracle
+    lib = c_oracle.load()
+    idx = np.array([0, 1, 2, 3, 1000, 2**33 + 5], dtype=np.uint64)
+    ref = O.philox_uniform(20250101, 7, idx)
+    got = np.array([lib.mcsas_c_philox_uniform(20250101, 7, int(i)) for i in idx])
+    np.testing.assert_array_equal(got, ref)
+    g = load("g4_sphere_q100_fixed.npz")
+    q, I, sig = g["data_q"], g["data_I"], g["data_sigma"]
+    lo, hi = float(g["spec_lo"][0]), float(g["spec_hi"][0])
+    spec = spec_for("sphere", [lo], [hi])
+    one = c_oracle.analyse_sphere(q, I, sig, lo, hi, 60, 5, 300, 1e-9, seed=11, rep_offset=2, threads=1)
+    par = c_oracle.analyse_sphere(q, I, sig, lo, hi, 60, 5, 300, 1e-9, seed=11, rep_offset=2, threads=3)
+    np.testing.assert_array_equal(one.contribs, par.contribs)
+    ost = O.Settings(n_contrib=60, n_reps=1, max_iter=300, conv_crit=1e-9)
+    for r in range(5):
+        ref = O.mc_fit(spec, q, I, sig, g["data_f_limit"], g["data_x0_limit"], ost, O.PhiloxStream(11, 2 + r), method="closed")
+        assert one.num_moves[r] == ref.num_moves
+        np.testing.assert_allclose(one.contribs[:, 0, r], ref.rset[:, 0], rtol=1e-15)
+        np.testing.assert_allclose(one.chisq[r], ref.conval, rtol=1e-9)
