@@ -52,6 +52,7 @@ def cpu_baseline(q, I, sigma, lo, hi, seconds_target=12.0):
     from oracle import mcsas_oracle as O
     from oracle import c_oracle
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(threads, int(os.environ.get("MCSAS_BENCH_CPU_THREADS", "16"))))   # one GPU's CPU share of the host
     c_oracle.load()
     probe = 20000
     t0 = time.time()
