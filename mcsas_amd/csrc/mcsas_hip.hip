@@ -452,7 +452,10 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         else if (waves > 1) mode = MCSAS_EXEC_WORKGROUP;
         else {
             PipeGeom pg; WgGeom wgm;
-            if (p->n_reps >= 1024) mode = MCSAS_EXEC_WAVE;
+            // measured crossovers (tools/mode_sweep.py, sphere 512 q x 400): the pipeline wins up to ~128 chains,
+            // one workgroup per chain up to ~400, one wavefront per chain beyond; rows that cost an integral
+            // each keep the workgroup's seven producer waves per chain until the chains alone fill the SIMDs
+            if (p->n_reps >= (heavy_rows ? 1024 : 448)) mode = MCSAS_EXEC_WAVE;
             else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
             else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
             else mode = MCSAS_EXEC_WAVE;
