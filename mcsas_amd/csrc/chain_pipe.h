@@ -2,9 +2,9 @@
 // with fewer chains than CUs (BASELINE config 2: 50 chains on 256 CUs).
 //
 // One launch per "tick" t (pipe_tick_kernel), two kinds of workgroup in its grid:
-//   scan blocks (one per chain, block ids 0..R-1) do SCAN(t): seven loader waves stage window t's d
-//       rows HBM -> LDS in sub-windows (loads issued one sub-window ahead), the scanner wave makes
-//       the accept/reject decisions eight steps at a time (same arithmetic as chain_wg.h);
+//   scan blocks (one per chain, block ids 0..R-1) do SCAN(t): eight waves stream window t's d rows
+//       HBM -> private LDS rings with LDS-DMA and reduce h = sum (w ft) d for their rows; wave 0 takes
+//       the accept/reject decisions 8 or 16 steps at a time (same arithmetic as chain_wg.h);
 //   producer blocks (the rest of the grid, every CU) do PROD(t+1): the form-factor rows of the NEXT
 //       window of Kb steps per chain -> `new` row into a spare HBM row slot, d = new - old and the
 //       three ft-independent sums into the window buffer in HBM.
@@ -46,7 +46,7 @@ struct PipeChain {                // per-chain scanner state, lives in HBM betwe
 
 struct PipeGeom {
     int32_t kb;                   // steps per window (tick)
-    int32_t ks;                   // steps per LDS sub-window in the scan kernel
+    int32_t ks;                   // steps per decision group after an accepted move (8; 16 after a group without one when the ring holds it)
     int32_t rows_per_wave;        // producer: rows per wave
     int32_t prod_blocks_y;        // producer grid.y
     int32_t scan_waves;           // scan kernel waves (1 scanner + loaders)
@@ -67,7 +67,7 @@ struct PipeArgs {
     double *pval;                 // [R][2][kb][MAX_ACTIVE]
     int32_t *povf;                // [R][2][kb]
     int32_t *n_done;              // host-mapped: number of finished chains
-    int32_t tick, pad;            // (tick travels as its own kernel argument)
+    int32_t tick, pad;            // unused: the tick travels as its own kernel argument
 };
 
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
