@@ -94,6 +94,12 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(const ChainArgs a) {
         }
         num_iter = 0; num_moves = 0;
         int ri = 0;
+        // The comparison chi²_t < chi² (mcsas.py:379) is made without divisions, as in the other kernels:
+        // chi²·Q = S - num²/den at the optimum (centred sums when a background is fitted), so
+        // chi²_t < chi²  <=>  num² > (S - X) den  with X = chi²·Q of the current state; the one division is
+        // paid when a move is accepted.  Scale and background are only needed at the end of the attempt.
+        const double nqd = (double)a.nq, invSw = 1.0 / a.Sw, SIoSw = a.SI / a.Sw, Scen = a.SII - a.SI * a.SI / a.Sw;
+        double X = cur.chi2 * nqd;
 
         // ------------------------------------------------------------ MC loop (mcsas.py:354-404)
         bool running = (N > 1);
@@ -146,9 +152,16 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(const ChainArgs a) {
                     s1 += wt; s2 += wt * test[j]; s3 += lwI[lane + WAVE * j] * test[j];
                 }
                 wave_sum3(s1, s2, s3);
-                const FitResult t = solve_fit(a, s1, s2, s3);                      // mcsas.py:376
-                if (t.chi2 < cur.chi2) {                                           // mcsas.py:379-390
-                    cur = t;
+                // s1 = Σ w C, s2 = Σ w C², s3 = Σ w I C of the candidate (mcsas.py:376)
+                double S = a.SII, num = s3, den = s2;
+                if (a.find_bg) {
+                    const double numc = s3 - SIoSw * s1, denc = s2 - s1 * invSw * s1;
+                    const bool neg_b = a.pos_bg && (a.SI * denc - numc * s1 < 0.);
+                    if (!neg_b) { S = Scen; num = numc; den = denc; }
+                }
+                if (num * num > (S - X) * den) {                                   // mcsas.py:379-390
+                    X = S - num * num / den;
+                    cur.chi2 = X / nqd;
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {
                         ft[j] = test[j];
