@@ -192,7 +192,7 @@ def main():
                                       "converged": int(conv.converged.sum()), "reps": args.reps,
                                       "chisq_max": float(conv.chisq.max()), "chisq_mean": float(conv.chisq.mean()),
                                       "steps_mean": float(conv.num_iter.mean()), "attempts_max": int(conv.attempts.max())}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:           # the CPU baseline is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(q, I, sigma, lo, hi)
         print(json.dumps(out))
     if use_dist:
