@@ -565,3 +565,40 @@ def test_random_configurations_all_modes_identical(case):
         for f in ("chisq", "scaling", "fit"):
             np.testing.assert_allclose(getattr(res, f), getattr(ref, f), rtol=1e-12, err_msg="%s differs in mode %d (%s nq=%d n=%d)" % (f, mode, tag, nq, n))
         np.testing.assert_allclose(res.background, ref.background, rtol=1e-9, atol=1e-12 * np.abs(I).max())
+
+
+def test_histogram_prep_equals_the_per_call_entry_points():
+    """mcsas_hip_histogram_prep (all repetitions in one call) against model_calc + bgfit + observability
+    called per repetition, and against the oracle's fractions (mcsas.py:549-594)."""
+    g = load("g45_analyse.npz")
+    q, I, sig = g["data_q"], g["data_I"], g["data_sigma"]
+    lo, hi = float(g["A_lo"]), float(g["A_hi"])
+    m, spec = make_models("sphere", [lo], [hi])
+    contribs = g["A_contribs"]
+    N, P, R = contribs.shape
+    sc, v, w, s, mv = engine.histogram_prep(m.setup(), q, I, sig, contribs, 0.6666666)
+    for r in range(R):
+        cum, v1, w1, s1 = engine.model_calc(m.setup(), q, contribs[:, :, r], 0.6666666)
+        sc1, _, _ = engine.bgfit(I, sig, cum, True, False, 1)
+        np.testing.assert_allclose(sc[:, r], sc1, rtol=1e-12)
+        np.testing.assert_array_equal(v[:, r], v1); np.testing.assert_array_equal(w[:, r], w1); np.testing.assert_array_equal(s[:, r], s1)
+    vf = w * sc[0][None, :] / v
+    mv1 = engine.observability(m.setup(), q, sig, contribs, sc[0], vf, 0.6666666)
+    np.testing.assert_allclose(mv, mv1, rtol=1e-9)
+    ost = O.Settings(n_contrib=N, n_reps=R, max_iter=1, conv_crit=5.0)
+    frac, oscal = O.fractions(spec, q, I, sig, g["data_f_limit"], ost, contribs, method="closed")
+    np.testing.assert_allclose(sc, oscal, rtol=1e-7)
+    np.testing.assert_allclose(vf, frac["vol"][0], rtol=1e-7)
+    np.testing.assert_allclose(mv, frac["vol"][1], rtol=1e-7)
+
+
+def test_uncertainty_floor_special_values():
+    """_prepareUncertainty's corner cases (dataobj/dataobj.py:204-227): the floor wins over smaller and over
+    zero uncertainties, non-finite results become +inf, negative intensities give a negative floor that the
+    given uncertainty beats."""
+    I = np.array([10.0, 10.0, 10.0, -4.0, 5.0, np.inf, 2.0])
+    su = np.array([0.01, 5.0, 0.0, 0.3, np.nan, 1.0, np.inf])
+    got = engine.prepare_uncertainty(I, su, 0.1)
+    ref = O.prepare_uncertainty(I, su, 0.1)
+    np.testing.assert_array_equal(got, ref)
+    assert got[0] == 1.0 and got[1] == 5.0 and got[2] == 1.0 and got[3] == 0.3 and np.isinf(got[4:]).all()
