@@ -2,16 +2,21 @@
 // with fewer chains than CUs (BASELINE config 2: 50 chains on 256 CUs).
 //
 // One launch per "tick" t (pipe_tick_kernel), two kinds of workgroup in its grid:
-//   scan blocks (one per chain, block ids 0..R-1) do SCAN(t): eight waves stream window t's d rows
-//       HBM -> private LDS rings with LDS-DMA and reduce h = sum (w ft) d for their rows; wave 0 takes
-//       the accept/reject decisions 8 or 16 steps at a time (same arithmetic as chain_wg.h);
-//   producer blocks (the rest of the grid, every CU) do PROD(t+1): the form-factor rows of the NEXT
-//       window of Kb steps per chain -> `new` row into a spare HBM row slot, d = new - old and the
-//       three ft-independent sums into the window buffer in HBM.
-// The two run concurrently inside one launch because a window's rows depend only on the random
-// stream and on row slots settled two windows earlier (2*Kb <= N), never on the decisions of the
-// window before.  Launch t+1 follows launch t on the same stream: the kernel boundary is the only
-// synchronisation; there are no in-kernel spin waits and no cross-workgroup flags.
+//   producer blocks (every CU) do PROD(t+1): the form-factor rows of the NEXT window of Kb steps per chain.
+//       A block owns one SUB-WINDOW of W = 8 * rows_per_wave consecutive steps: `new` row into a spare HBM
+//       row slot, d = new - old and the three ft-independent sums (a = Σ w d, e = Σ wI d, g = Σ w d²) into the
+//       window buffer, and then — fp64 MFMA, v_mfma_f64_16x16x4_f64 — the sub-window's Gram block
+//       G[a][k] = Σ_q w d_a d_k, which does not depend on ft either.
+//   scan blocks (one per chain) do SCAN(t): per sub-window ONE pass over its d rows gives h_k = Σ (w ft) d_k for
+//       the ft the sub-window starts from (eight waves, rows streamed HBM/L2 -> registers); then ONE wave takes
+//       the W decisions with lane g = step g: a candidate's fit sums are SC + a, SIC + e, SCC + 2h + g, and after
+//       an accepted row `acc` the later steps of the sub-window need only h_k += G[acc][k] (one LDS read) — no
+//       barrier, no re-reduction and no restart per accepted move; the accepted rows are applied to ft once per
+//       sub-window, in order, as (ft - old) + new like mcsas.py:367.
+// PROD(t+1) and SCAN(t) run concurrently inside one launch because a window's rows depend only on the random
+// stream and on row slots settled two windows earlier (2*Kb <= N), never on the decisions of the window
+// before.  Launch t+1 follows launch t on the same stream: the kernel boundary is the only synchronisation
+// between workgroups; there are no in-kernel spin waits and no cross-workgroup flags.
 //
 // Chain schedule: an attempt (one mcFit call) is initialised at tick t_init (PROD evaluates the N
 // rows of the initial set, SCAN sums them and fits), then tick t > t_init handles window
@@ -25,6 +30,9 @@ namespace mcsas {
 // Keep a wave-uniform double in a VGPR: the scan loop has far more uniform fp64 state than the 102
 // SGPRs can hold, and spilled SGPRs come back one v_readlane at a time on the critical path.
 #define MCSAS_IN_VGPR(x) asm volatile("" : "+v"(x))
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double v2f64 __attribute__((ext_vector_type(2)));
 
 struct PipeSnap {                 // what the producer needs to know about a chain
     int32_t attempt, t_init, alive, pad;
@@ -46,12 +54,12 @@ struct PipeChain {                // per-chain scanner state, lives in HBM betwe
 
 struct PipeGeom {
     int32_t kb;                   // steps per window (tick)
-    int32_t ks;                   // steps per decision group after an accepted move (8; 16 after a group without one when the ring holds it)
+    int32_t w;                    // steps per sub-window = rows per producer block = 8 * rows_per_wave (<= 64)
     int32_t rows_per_wave;        // producer: rows per wave
-    int32_t prod_blocks_y;        // producer grid.y
-    int32_t scan_waves;           // scan kernel waves (1 scanner + loaders)
+    int32_t prod_blocks_y;        // producer blocks (= sub-windows) per chain and tick
+    int32_t scan_waves;           // waves of a scan block
     int32_t qpl;
-    int32_t ring, pad;            // rows each scan wave keeps in its private LDS ring (4, 2 or 1)
+    int32_t gram_off, pad;        // producer LDS: offset (doubles) of the Gram reduction buffer
     uint64_t prod_lds, scan_lds;
 };
 
@@ -62,7 +70,8 @@ struct PipeArgs {
     double *ft, *wft;             // [R][qpad]
     int32_t *slot_of;             // [R][N]
     int32_t *stage_slot;          // [R][2][kb]
-    double *dwin;                 // [R][2][kb][qpad]
+    double *dwin;                 // [R][2][kb][qpad]   d rows of the window
+    double *gwin;                 // [R][2][kb][w]      Gram blocks: row = step in the window, column = step in ITS sub-window
     double *scal;                 // [R][2][kb][4]
     double *pval;                 // [R][2][kb][MAX_ACTIVE]
     int32_t *povf;                // [R][2][kb]
@@ -71,39 +80,151 @@ struct PipeArgs {
 };
 
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
-constexpr int PIPE_RING = 4;         // most rows a scan wave keeps in flight in its private LDS ring
+constexpr int PIPE_WAVES = PIPE_BLOCK / 64;
+constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
-static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, PipeGeom *g) {
+// rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
+static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, PipeGeom *g) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
     const int qpad = qpl * 64;
     // window: as many steps as 2*Kb <= N allows (a multiple of the 8 producer waves x rows per wave)
     int rpw = 8;
-    while (rpw > 1 && 2 * 8 * rpw > n_contrib) rpw /= 2;
+    if (rows_per_wave_req >= 1 && rows_per_wave_req <= 8) rpw = rows_per_wave_req;
+    // rows that cost a numerical integration each (cylinders, ellipsoids, worm-like chains): one row per
+    // producer wave, so that a window is R*Kb waves for the 1024 SIMDs instead of R*Kb/8
+    else if (heavy_rows) rpw = 1;
+    while (rpw > 1 && 2 * 8 * rpw > n_contrib) --rpw;
     if (2 * 8 * rpw > n_contrib) return 1;
     int by = n_contrib / (2 * 8 * rpw);
     if (by * 8 * rpw > 256) by = 256 / (8 * rpw);
-    g->kb = by * 8 * rpw; g->qpl = qpl;
-    // rows that cost a numerical integration each (cylinders, ellipsoids, worm-like chains): one row per
-    // producer wave, so that a window is R*Kb waves for the 1024 SIMDs instead of R*Kb/8
-    if (heavy_rows) { by *= rpw; rpw = 1; }
+    g->kb = by * 8 * rpw; g->qpl = qpl; g->w = 8 * rpw;
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
-    g->prod_lds = sizeof(double) * (4 * (size_t)qpad + tab_doubles);
-    // scan block LDS: one private ring of `ring` rows per wave + the window's scalars/tables
-    g->ks = 8; g->scan_waves = PIPE_BLOCK / 64;
-    for (int ring = PIPE_RING; ring >= 1; ring /= 2) {
-        g->ring = ring;
-        g->scan_lds = sizeof(double) * ((size_t)g->scan_waves * ring * qpad + (size_t)g->kb * 4 + 16)
-                    + sizeof(int32_t) * (4 * g->kb + 32) + 64;
-        if (g->scan_lds <= 160 * 1024) break;
-    }
-    if (g->scan_lds > 160 * 1024) return 1;
+    g->gram_off = 4 * qpad + tab_doubles;
+    g->prod_lds = sizeof(double) * ((size_t)g->gram_off + (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256);
+    g->scan_waves = PIPE_WAVES;
+    // scan block LDS: two Gram blocks (double buffer), ft and w*ft, the window's scalars, h of the sub-window,
+    // flags / slot tables / accepted lists
+    g->scan_lds = sizeof(double) * (2 * (size_t)g->w * g->w + 2 * (size_t)qpad + (size_t)g->kb * 4 + 64)
+                + sizeof(int32_t) * (4 * (size_t)g->kb + 1 + 2 * 64 + 4 + 8) + 64;
+    if (g->scan_lds > 160 * 1024 || g->prod_lds > 160 * 1024) return 1;
     return 0;
 }
 
+// one row of the window buffers as every kernel here holds it in registers: 16-byte loads, lane l and
+// register pair c <-> q = 128 c + 2 l + {0, 1}  (QPL = 1: one 8-byte load, q = l)
+template <int QPL>
+__device__ __forceinline__ void load_row_pairs(const double *row, int lane, double (&r)[QPL]) {
+    if constexpr (QPL >= 2) {
+#pragma unroll
+        for (int c = 0; c < QPL / 2; ++c) {
+            const v2f64 v = *reinterpret_cast<const v2f64 *>(row + 128 * c + 2 * lane);
+            r[2 * c] = v.x; r[2 * c + 1] = v.y;
+        }
+    } else {
+        r[0] = row[lane];
+    }
+}
+
 // ------------------------------------------------------------------------------------ producer
+// Gram block of one sub-window, G[a][k] = Σ_q w_q d_a(q) d_k(q) over the W rows this block has just written,
+// with v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) B(4x16), lane l supplies A[l % 16][l / 16] and
+// B[l / 16][l % 16], result register r holds D[4 r + l / 16][l % 16].  With A = d rows and B = (w d) rows both
+// operands of lane l are the SAME element (row l % 16, q-slot l / 16) — one load, one multiply, one MFMA.
+// Wave v takes the q slice [v 8 QPL, (v + 1) 8 QPL) for ALL tiles (every row element is loaded exactly once
+// per block); its load number c covers 8 consecutive q of the slice, two per lane slot kk = l / 16 (any
+// assignment of q to MFMA k-slots is fine, the sum runs over all of them): the four slots of a row read 64
+// contiguous bytes, so a 128-byte line is consumed by two consecutive loads instead of lingering in L1.
+// The eight partial tiles are then summed in wave order through LDS (deterministic) and written to
+// gout[a][k], a, k < W.
+template <int QPL>
+__device__ __forceinline__ void pipe_prod_gram(const double *drows, int qpad, int W, int nvalid, const double *lw,
+                                               double *gred, double *gout) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, kk = lane >> 4;
+    const int T = (W + 15) >> 4;                              // 16-row groups (<= 4)
+    const int qs = wave * (8 * QPL) + kk * 2;
+    v4f64 acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = (v4f64){0., 0., 0., 0.};
+    const double *rowp[4];
+    bool rowok[4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+        const int rr = 16 * gi + m;
+        rowok[gi] = gi < T && rr < nvalid;
+        rowp[gi] = drows + (size_t)(rowok[gi] ? rr : 0) * qpad + qs;
+    }
+    // loads run one step-pair ahead of the MFMAs that consume them (an L2 round trip per step-pair otherwise)
+    v2f64 nxt[4], wnx;
+    auto fetch = [&](int s, v2f64 (&dst)[4], v2f64 &wdst) {
+        wdst = *reinterpret_cast<const v2f64 *>(lw + qs + 4 * s);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            dst[gi] = (v2f64){0., 0.};
+            if (gi < T) dst[gi] = *reinterpret_cast<const v2f64 *>(rowp[gi] + 4 * s);
+        }
+    };
+    fetch(0, nxt, wnx);
+#pragma unroll
+    for (int s = 0; s < 2 * QPL; s += 2) {
+        v2f64 av[4], bv[4];
+        const v2f64 wv = wnx;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) av[gi] = rowok[gi] ? nxt[gi] : (v2f64){0., 0.};
+        if (s + 2 < 2 * QPL) fetch(s + 2, nxt, wnx);
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) bv[gi] = av[gi] * wv;
+        int ti = 0;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+            for (int gj = gi; gj < 4; ++gj) {
+                if (gj < T) {
+                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].x, bv[gj].x, acc[ti], 0, 0, 0);
+                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].y, bv[gj].y, acc[ti], 0, 0, 0);
+                }
+                ++ti;
+            }
+    }
+    // cross-wave sum, PIPE_GRAM_TILES_PER_ROUND tiles per round
+    constexpr int TPR = PIPE_GRAM_TILES_PER_ROUND;
+#pragma unroll
+    for (int r0 = 0; r0 < 10; r0 += TPR) {
+        bool any = false;                                     // does this round hold a tile with gj < T ?
+        {
+            int ti = 0;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+                for (int gj = gi; gj < 4; ++gj) { if (ti >= r0 && ti < r0 + TPR && gj < T) any = true; ++ti; }
+        }
+        if (!any) continue;                                   // uniform for the block
+#pragma unroll
+        for (int u = 0; u < TPR; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gred[((size_t)(wave * TPR + u) * 4 + r) * 64 + lane] = acc[r0 + u][r];
+        __syncthreads();
+        {
+            const int u = tid >> 8, idx = tid & 255;          // 512 threads <-> TPR (= 2) tiles x 256 elements
+            double sum = 0.;
+#pragma unroll
+            for (int v = 0; v < PIPE_WAVES; ++v) sum += gred[(size_t)(v * TPR + u) * 256 + idx];
+            int ti = 0, tgi = -1, tgj = -1;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+                for (int gj = gi; gj < 4; ++gj) { if (ti == r0 + u) { tgi = gi; tgj = gj; } ++ti; }
+            const int i = 4 * (idx >> 6) + ((idx & 63) >> 4), j = idx & 15;
+            const int ar = 16 * tgi + i, kc = 16 * tgj + j;
+            if (tgi >= 0 && tgj < T && ar < W && kc < W) gout[(size_t)ar * W + kc] = sum;
+        }
+        __syncthreads();
+    }
+}
+
 template <int M, int QPL>
 __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds, int rep, int by, int gy, int t) {
     const ChainArgs &a = pa.c;
@@ -170,11 +291,12 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     }
 
     if (a.pad0 & 16) return;                                  // diagnostic: no window rows
+    MCSAS_STAMP_DECL(pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0);
+    MCSAS_STAMP(pp0);
     // ---- window w of the attempt: this wave's rows k = gw*rpw .. +rpw-1, one proposal per lane
     const int64_t w = (int64_t)t - sn.t_init - 1;
     const int rpw = pa.g.rows_per_wave, buf = t & 1;
     const int k0 = gw * rpw;
-    if (k0 >= Kb) return;
     const int64_t s0 = w * Kb + k0;
     double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
     int pov = 0;
@@ -195,12 +317,19 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     double *pval = pa.pval + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
     int32_t *povf = pa.povf + ((size_t)rep * 2 + buf) * Kb;
     int ri = (int)(s0 % N);
+    // row slots of all my rows in one round trip (lane i <-> my row i): the row loop below then starts its loads
+    // of `old` without waiting for a dependent index load per row
+    int my_oslot = 0, my_sslot = 0;
+    if (lane < rpw) {
+        int r = ri + lane; if (r >= N) r -= N;
+        my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + k0 + lane];
+    }
     for (int i = 0; i < rpw; ++i) {
         const int k = k0 + i;
         if (s0 + i >= a.max_iter) break;
         const int bl = __builtin_amdgcn_readfirstlane(i);
         const Contrib<M> cnew = prop.bcast(bl);
-        const int oslot = slot_of[ri], sslot = stage[buf * Kb + k];
+        const int oslot = __builtin_amdgcn_readlane(my_oslot, bl), sslot = __builtin_amdgcn_readlane(my_sslot, bl);
         const double *orow = cache + (size_t)oslot * qpad + lane;
         double *nrow = cache + (size_t)sslot * qpad + lane;
         double *dr = dwin + (size_t)k * qpad + lane;
@@ -230,17 +359,42 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
         if (lane == 0) povf[k] = ov;
         ri = (ri + 1 == N) ? 0 : ri + 1;
     }
+    // ---- the sub-window's Gram block from the d rows the block has just written (workgroup-scope visibility:
+    // the barrier's fence; same CU, same L1)
+    if (a.pad0 & 64) return;                                  // diagnostic: no Gram blocks
+    MCSAS_STAMP(pp1);
+    __syncthreads();
+    MCSAS_STAMP(pp2);
+    {
+        const int W = pa.g.w;
+        const int64_t left = a.max_iter - (w * Kb + (int64_t)by * W);
+        const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
+        if (nvalid > 1)
+            pipe_prod_gram<QPL>(dwin + (size_t)by * W * qpad, qpad, W, nvalid, lw, lds + pa.g.gram_off,
+                                pa.gwin + (((size_t)rep * 2 + buf) * Kb + (size_t)by * W) * W);
+    }
+#ifdef MCSAS_STAMPS
+    MCSAS_STAMP(pp3);
+    if (by == 0 && tid == 0) {                                // wave 0 of the chain's first producer block
+        PipeChain &chs = pa.chains[rep];
+        atomicAdd((unsigned long long *)&chs.dbg[8], (unsigned long long)(pp1 - pp0));
+        atomicAdd((unsigned long long *)&chs.dbg[9], (unsigned long long)(pp2 - pp1));
+        atomicAdd((unsigned long long *)&chs.dbg[10], (unsigned long long)(pp3 - pp2));
+        atomicAdd((unsigned long long *)&chs.dbg[11], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ scanner
-// LDS: one ring of `ring` rows per wave; the window's scalars, flags and slot tables; control words
+// LDS: two Gram blocks, ft and w*ft, the window's scalars, h of the current sub-window, flags and slot tables
 template <int QPL>
 __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds, int rep, int t, int stop_now) {
+    static_assert(PIPE_GRAM_TILES_PER_ROUND * 256 == PIPE_BLOCK, "Gram reduction maps one thread to one tile element");
     const ChainArgs &a = pa.c;
     // the wave index is wave-uniform: keep it (and the row bookkeeping that hangs on it) on the scalar unit
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb;
-    const int NW = pa.g.scan_waves, T = NW * WAVE;
+    const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb, W = pa.g.w, RPW = pa.g.rows_per_wave;
+    constexpr int T = PIPE_BLOCK;
     PipeChain &ch = pa.chains[rep];
     if (ch.done) return;                                      // uniform for the block
     MCSAS_STAMP_DECL(sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0);
@@ -250,19 +404,22 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #endif
     const PipeSnap sn = ch.snap[(t + 1) & 1];                 // the record in force for tick t (written at t-1; host for t = 0)
 
-    const int RING = pa.g.ring, RMASK = RING - 1;             // ring depth is 4, 2 or 1
-    double *ring = lds + (size_t)wave * RING * qpad;                       // this wave's RING rows
-    double *ssub = lds + (size_t)NW * RING * qpad;                   // [Kb][4] scalars of the whole window
-    double *hbuf = ssub + (size_t)Kb * 4;                                  // [8] h of the current group, by step offset
-    int32_t *osub = reinterpret_cast<int32_t *>(hbuf + 16);                // [Kb] replay-overflow flags
-    int32_t *lstage = osub + Kb, *lslot = lstage + Kb;          // [Kb] spare row slot of step k / row slot of its contribution
-    int32_t *lacc = lslot + Kb;                                // [Kb + 1] accepted steps of this window, count in lacc[Kb]
-    int32_t *ctl = lacc + Kb + 1;                              // [k_next, accepted row or -1, live]
+    double *Gl = lds;                                         // [2][W*W] Gram block of the current / next sub-window
+    double *lft = Gl + 2 * (size_t)W * W;                     // [qpad] ft, q-indexed
+    double *lwft = lft + qpad;                                // [qpad] w * ft
+    double *ssub = lwft + qpad;                               // [Kb][4] scalars of the whole window
+    double *hbuf = ssub + (size_t)Kb * 4;                     // [64] h of the current sub-window, by step offset
+    int32_t *osub = reinterpret_cast<int32_t *>(hbuf + 64);   // [Kb] replay-overflow flags
+    int32_t *lstage = osub + Kb, *lslot = lstage + Kb;        // [Kb] spare row slot of step k / row slot of its contribution
+    int32_t *lacc = lslot + Kb;                               // [Kb + 1] accepted steps of this window, count in lacc[Kb]
+    int32_t *sacc = lacc + Kb + 1;                            // [1 + 2*64] this sub-window: count, then (old slot, new slot) per accepted step
+    int32_t *ctl = sacc + 1 + 2 * 64;                         // [4]: [2] = live
     double *gft = pa.ft + (size_t)rep * qpad, *gwft = pa.wft + (size_t)rep * qpad;
     double *rset = a.rset + (size_t)rep * N * P;
     double *cache = a.cache + (size_t)rep * a.cache_rows * qpad;
     const int buf = t & 1;
     const double *dwin = pa.dwin + ((size_t)rep * 2 + buf) * Kb * qpad;
+    const double *gwin = pa.gwin + ((size_t)rep * 2 + buf) * Kb * W;
     const double *scal = pa.scal + ((size_t)rep * 2 + buf) * Kb * 4;
     const double *pval = pa.pval + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
     const int32_t *povf = pa.povf + ((size_t)rep * 2 + buf) * Kb;
@@ -294,6 +451,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 const double wf = a.w[lane + WAVE * j] * ft[j];
                 s1 += wf; s2 += wf * ft[j]; s3 += a.wI[lane + WAVE * j] * ft[j];
                 gft[lane + WAVE * j] = ft[j]; gwft[lane + WAVE * j] = wf;
+                lft[lane + WAVE * j] = ft[j];                 // the end-of-attempt code below reads ft from LDS
             }
             wave_sum3(s1, s2, s3);
             SC = s1; SCC = s2; SIC = s3;
@@ -302,41 +460,42 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             if (N <= 1 || a.max_iter <= 0 || !(cur.chi2 > a.conv_crit)) attempt_over = true;
         }
     } else {
-        // ---- window w = t - t_init - 1.  Eight symmetric waves: wave v owns the window's rows r = v (mod 8),
-        // streams them from HBM into its private LDS ring with LDS-DMA (PIPE_RING rows in flight, no
-        // registers), computes h = Σ (w ft) d for its rows of the current group of steps, and wave 0
-        // decides the group.
+        // ---- window w = t - t_init - 1, sub-window by sub-window
         const int64_t w = (int64_t)t - sn.t_init - 1;
         const int64_t budget = a.max_iter - w * Kb;
         const int kmax_all = budget < Kb ? (budget < 0 ? 0 : (int)budget) : Kb;
         const int ri0 = (int)((w * Kb) % N);
-        const bool dbg_noload = a.pad0 & 4, dbg_noscan = a.pad0 & 8;
-        typedef __attribute__((address_space(3))) void *lds_vp;
-        typedef __attribute__((address_space(1))) const void *glb_vp;
-        constexpr int CALLS = (QPL >= 2) ? QPL / 2 : 1;        // 1 KB DMA calls per row (QPL = 1: half a call, 32 lanes)
-        const bool dma_lane = (QPL >= 2) || lane < 32;
-        auto issue_row = [&](int m) {                          // m-th row of this wave: r = wave + 8 m
-            const char *gsrc = reinterpret_cast<const char *>(dwin + (size_t)(wave + 8 * m) * qpad) + lane * 16;
-            double *ldst = ring + (size_t)(m & RMASK) * qpad;
-            if (dma_lane) {
+        const int nsub = (kmax_all + W - 1) / W;
+        // rows in registers: RB rows per batch, two batches (one being reduced, one in flight)
+        constexpr int RB = (QPL <= 4) ? 4 : (QPL == 8 ? 2 : 1);    // 16 doubles per set at most
+        const int NB = (RPW + RB - 1) / RB;                   // batches per sub-window
+        // row `i` (0..RPW-1) of this wave in sub-window s is step s W + wave + 8 i
+        auto load_batch = [&](int s, int b, double (&rb)[RB][QPL]) {
 #pragma unroll
-                for (int c = 0; c < CALLS; ++c)
-                    __builtin_amdgcn_global_load_lds((glb_vp)(gsrc + c * 1024), (lds_vp)(ldst + c * 128), 16, 0, 0);
+            for (int x = 0; x < RB; ++x) {
+                const int g = wave + 8 * (b * RB + x), k = s * W + g;
+                const bool ok = (b * RB + x) < RPW && k < kmax_all;
+                load_row_pairs<QPL>(dwin + (size_t)(ok ? k : 0) * qpad, lane, rb[x]);
             }
         };
-        // The whole prologue is ONE memory round trip: the first ring rows go out first, then every
-        // other load of the block, and only then the single wait.
-        const int my_rows = (kmax_all > wave) ? (kmax_all - wave + 7) / 8 : 0;   // rows this wave owns
-        int m_issue = 0, m_cur = 0;
-        if (!dbg_noload)
-            for (; m_issue < RING && m_issue < my_rows; ++m_issue) issue_row(m_issue);
-        // every wave keeps its own copy of ft, w*ft and w in registers and applies accepted rows to it
-        // itself (same two operations in every wave, so the copies stay bit-identical)
-        double wftr[QPL], ftr[QPL], wr[QPL], wIr[QPL];
+        // Gram block of sub-window s -> LDS buffer s & 1 (W*W doubles, contiguous in HBM)
+        auto load_gram = [&](int s) {
+            const int cnt = W * W;
+            const double *src = gwin + (size_t)s * W * W;
+            double *dst = Gl + (size_t)(s & 1) * W * W;
+            for (int i = 2 * tid; i < cnt; i += 2 * T)
+                *reinterpret_cast<v2f64 *>(dst + i) = *reinterpret_cast<const v2f64 *>(src + i);
+        };
+        double rbA[RB][QPL], rbB[RB][QPL];
+        if (nsub > 0) { load_batch(0, 0, rbA); load_gram(0); }
+        // ft, w ft -> LDS; the thread's own q (apply phase): q = tid (+ 512)
+        constexpr int QT = (QPL * 64 + T - 1) / T;            // q per thread in the apply phase (1 or 2)
+        double wq[QT];
 #pragma unroll
-        for (int j = 0; j < QPL; ++j) {
-            const int i = lane + WAVE * j;
-            wr[j] = a.w[i]; wIr[j] = a.wI[i]; ftr[j] = gft[i]; wftr[j] = gwft[i];
+        for (int x = 0; x < QT; ++x) {
+            const int i = tid + T * x;
+            wq[x] = 0.;
+            if (i < qpad) { wq[x] = a.w[i]; lft[i] = gft[i]; lwft[i] = gwft[i]; }
         }
         {
             const int n4 = kmax_all * 4;                       // Kb <= 256: at most two scalars per thread
@@ -353,21 +512,19 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             if (tid + PIPE_BLOCK < n4) ssub[tid + PIPE_BLOCK] = sv1;
             if (tid < kmax_all) { osub[tid] = ov; lstage[tid] = stg; lslot[tid] = sl; }
         }
-        if (tid == 0) lacc[Kb] = 0;
+        if (tid == 0) { lacc[Kb] = 0; sacc[0] = 0; }
         const double invSw = 1.0 / a.Sw, SIoSw = a.SI / a.Sw, Scen = a.SII - a.SI * a.SI / a.Sw;
         double X = cur.chi2 * nqd;
         bool touched = false, live = true;
         int num_acc_win = 0;
         if (wave == 0) {
-            __builtin_amdgcn_s_setprio(1);
             if (stop_now) stopped = 1;                         // McSAS.stop as the host saw it when it launched this tick
             if (lane == 0) ctl[2] = (!(cur.chi2 > a.conv_crit) || stopped) ? 0 : 1;   // `live`, shared by all waves
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int k = 0;
+        __syncthreads();
         live = ctl[2] != 0;
-        if (dbg_noscan) { num_iter += kmax_all; k = kmax_all; }
+        double wftp[QPL];
+        load_row_pairs<QPL>(lwft, lane, wftp);
         // loop-invariant fit constants and the running sums, pinned in VGPRs (see MCSAS_IN_VGPR)
         double cSII = a.SII, cSI = a.SI, cScen = Scen, cSIoSw = SIoSw, cinvSw = invSw, cCrit = a.conv_crit, cnq = nqd;
         MCSAS_IN_VGPR(cSII); MCSAS_IN_VGPR(cSI); MCSAS_IN_VGPR(cScen); MCSAS_IN_VGPR(cSIoSw); MCSAS_IN_VGPR(cinvSw);
@@ -375,165 +532,161 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         MCSAS_IN_VGPR(SC); MCSAS_IN_VGPR(SIC); MCSAS_IN_VGPR(SCC); MCSAS_IN_VGPR(X);
         const bool find_bg = a.find_bg, pos_bg = a.pos_bg, never_accept = a.pad0 & 32;
 #ifdef MCSAS_STAMPS
-        int64_t ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        int64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-        MCSAS_STAMP_DECL(s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0, s8 = 0, s9 = 0);
-        // Steps are decided in groups: 8 after a group that accepted a move, 16 after one that did not
-        // (moves come in bursts early in a run and become rare later; a longer group amortises the fixed
-        // LDS round trips and barriers).  Wave v contributes its rows r = v (mod 8) of the group.
-        const int GMAX = (RING >= 4) ? 16 : 8;
-        int G = 8;
-        const int g16 = lane & 15;
+        MCSAS_STAMP_DECL(s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0);
         MCSAS_STAMP(sb1);
-        while (k < kmax_all && live) {
+        for (int s = 0; s < nsub && live; ++s) {
             MCSAS_STAMP(s0);
-            const int gcount = (kmax_all - k) < G ? (kmax_all - k) : G;
-            // my rows of this group (if any): r0 = the smallest r >= k with r = wave (mod 8), then r0 + 8
-            const int r0 = k + ((wave - (k & 7) + 8) & 7);
-            const int m0 = r0 >> 3;
-            const bool mine = r0 < k + gcount, mine1 = r0 + 8 < k + gcount;
-            const int mlast = mine1 ? m0 + 1 : m0;
-            // (rows behind the group start are normally retired and the ring refilled AFTER the barrier,
-            // while the decision is being taken, so the DMA issue costs the critical path nothing; only a
-            // ring too shallow to hold the next row has to catch up here)
-            while (mine && m_issue <= mlast && m_cur < m0 && !dbg_noload) {
-                ++m_cur;
-                if (m_issue < my_rows) { issue_row(m_issue); ++m_issue; }
-            }
-            MCSAS_STAMP(s1);
-            if (mine) {
-                // wait until my last row of the group has landed: only younger rows' DMAs may be in flight
-                const int younger = m_issue - 1 - mlast;
-                if (younger >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CALLS) : "memory");
-                else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CALLS) : "memory");
-                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * CALLS) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                MCSAS_STAMP(s2);
-                const double *dr = ring + (size_t)(m0 & RMASK) * qpad + lane;
-                const double *dr1 = ring + (size_t)((m0 + 1) & RMASK) * qpad + lane;
-                double h0 = 0., h1 = 0., e0 = 0., e1 = 0.;
+            const int k0 = s * W;
+            const int cnt = (kmax_all - k0) < W ? (kmax_all - k0) : W;
+            if (s + 1 < nsub) load_gram(s + 1);                // its buffer was last read two sub-windows ago
+            // ---- h_k = Σ (w ft) d_k for my rows of this sub-window: batches alternate between the two register sets
+            double acc[8];
 #pragma unroll
-                for (int j = 0; j < QPL; j += 2) {
-                    h0 = fma(wftr[j], dr[WAVE * j], h0);
-                    if (j + 1 < QPL) h1 = fma(wftr[j + 1], dr[WAVE * (j + 1)], h1);
-                }
-                if (mine1) {
+            for (int i = 0; i < 8; ++i) acc[i] = 0.;
+            auto reduce_batch = [&](int b, const double (&rb)[RB][QPL]) {
+#pragma unroll
+                for (int x = 0; x < RB; ++x) {
+                    double h0 = 0., h1 = 0.;
 #pragma unroll
                     for (int j = 0; j < QPL; j += 2) {
-                        e0 = fma(wftr[j], dr1[WAVE * j], e0);
-                        if (j + 1 < QPL) e1 = fma(wftr[j + 1], dr1[WAVE * (j + 1)], e1);
+                        h0 = fma(wftp[j], rb[x][j], h0);
+                        if (j + 1 < QPL) h1 = fma(wftp[j + 1], rb[x][j + 1], h1);
+                    }
+                    const double hs = h0 + h1;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) if (i == b * RB + x) acc[i] = hs;
+                }
+            };
+#pragma unroll
+            for (int b = 0; b < 8 / RB; b += 2) {
+                if (b < NB) {
+                    // next batch into set B: the next one of this sub-window, or the first of the next sub-window
+                    if (b + 1 < NB) load_batch(s, b + 1, rbB);
+                    else if (s + 1 < nsub) load_batch(s + 1, 0, rbB);
+                    reduce_batch(b, rbA);
+                    if (b + 1 < NB) {
+                        if (b + 2 < NB) load_batch(s, b + 2, rbA);
+                        else if (s + 1 < nsub) load_batch(s + 1, 0, rbA);
+                        reduce_batch(b + 1, rbB);
+                    } else {
+                        // odd batch count: the prefetched first batch of the next sub-window sits in set B
+#pragma unroll
+                        for (int x = 0; x < RB; ++x)
+#pragma unroll
+                            for (int j = 0; j < QPL; ++j) rbA[x][j] = rbB[x][j];
                     }
                 }
-                double hs = h0 + h1, es = e0 + e1;
-                MCSAS_STAMP(s3);
-                if (mine1) wave_sum2(hs, es); else hs = wave_sum(hs);
-                MCSAS_STAMP(s4);
-                if (lane == 0) { hbuf[r0 - k] = hs; if (mine1) hbuf[r0 + 8 - k] = es; }
             }
-            // the scalars of my lane's step do not depend on the other waves: fetch them before the barrier
-            const int kg = (k + g16 < kmax_all) ? k + g16 : kmax_all - 1;
-            double sc0 = 0., sc1 = 0., sc2 = 0.;
-            int ovg = 0;
-            if (wave == 0) { const double *sc = ssub + kg * 4; sc0 = sc[0]; sc1 = sc[1]; sc2 = sc[2]; ovg = osub[kg]; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            MCSAS_STAMP(s5);
-            __builtin_amdgcn_s_barrier();                                  // B1: hbuf complete
-            MCSAS_STAMP(s6);
-            if (wave != 0) {
-                // workers: retire the rows behind this group's start and refill the ring while wave 0 decides
-                const int m_keep = (k + ((wave - (k & 7) + 8) & 7)) >> 3;   // my first row at or after k
-                while (m_cur < m_keep) {
-                    ++m_cur;
-                    if (m_issue < my_rows && !dbg_noload) { issue_row(m_issue); ++m_issue; }
-                }
+            {
+                // eight sums for the price of ~1.5: lane l < 8 ends up with the total of acc[4 (l&1) + 2 ((l>>1)&1) + ((l>>2)&1)]
+                const double tot = wave_sum8_transposed(acc, lane);
+                const int c = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
+                if (lane < 8 && c < RPW && wave + 8 * c < cnt) hbuf[wave + 8 * c] = tot;
             }
+            MCSAS_STAMP(s1);
+            __syncthreads();                                               // B1: hbuf (and this sub-window's Gram block) complete
+            MCSAS_STAMP(s2);
             if (wave == 0) {
-                // lane g decides step k+g (all groups of 16 lanes do the same work)
-                const double h = hbuf[g16];
-                const double SCt = SC + sc0, SICt = SIC + sc1, SCCt = SCC + (2. * h + sc2);
-                // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
-                double S = cSII, num = SICt, den = SCCt;
-                if (find_bg) {
-                    const double numc = SICt - cSIoSw * SCt, denc = SCCt - SCt * cinvSw * SCt;
-                    const bool neg_b = pos_bg && (cSI * denc - numc * SCt < 0.);
-                    if (!neg_b) { S = cScen; num = numc; den = denc; }
-                }
-                const bool acc_g = (g16 < gcount) && (num * num > (S - X) * den);   // chi²_t < chi² (mcsas.py:379)
-                unsigned amask = (unsigned)(__ballot(acc_g) & 0xFFFFull);
-                if (never_accept) amask = 0u;                       // diagnostic: never accept
-                const unsigned ovm = (unsigned)(__ballot((g16 < gcount) && ovg) & 0xFFFFull);
-                int k_next, acc_row = -1, g_next = GMAX;
-                if (amask == 0u) {
-                    if (ovm) overflow = 1;
-                    k_next = k + gcount; num_iter += gcount;
-                } else {
-                    const int ga = __builtin_ctz(amask);
-                    if (ovm & ((2u << ga) - 1u)) overflow = 1;
-                    acc_row = k + ga;
-                    g_next = 8;
-                    SC = readlane_f64(SCt, ga); SIC = readlane_f64(SICt, ga); SCC = readlane_f64(SCCt, ga);
-                    // chi²·Q of the accepted state from the same three numbers the decision used (one
-                    // division); scale and background are only needed at the end of the attempt
-                    X = readlane_f64(S - num * num / den, ga);
-                    MCSAS_IN_VGPR(SC); MCSAS_IN_VGPR(SIC); MCSAS_IN_VGPR(SCC); MCSAS_IN_VGPR(X);
-                    cur.chi2 = X / cnq;
+                // ---- the W decisions of the sub-window: lane g <-> step k0 + g
+                __builtin_amdgcn_s_setprio(1);
+                const int g = lane;
+                const bool in = g < cnt;
+                const int kg = in ? k0 + g : k0;
+                double h = hbuf[in ? g : 0];
+                const double sc0 = ssub[kg * 4 + 0], sc1 = ssub[kg * 4 + 1], sc2 = ssub[kg * 4 + 2];
+                const int ovg = osub[kg];
+                const double *Gs = Gl + (size_t)(s & 1) * W * W;
+                int start = 0, nacc_sub = 0;
+                for (;;) {
+                    const double SCt = SC + sc0, SICt = SIC + sc1, SCCt = SCC + (2. * h + sc2);
+                    // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
+                    double S = cSII, num = SICt, den = SCCt;
+                    if (find_bg) {
+                        const double numc = SICt - cSIoSw * SCt, denc = SCCt - SCt * cinvSw * SCt;
+                        const bool neg_b = pos_bg && (cSI * denc - numc * SCt < 0.);
+                        if (!neg_b) { S = cScen; num = numc; den = denc; }
+                    }
+                    const bool cand = in && g >= start;
+                    const bool acc_g = cand && (num * num > (S - X) * den);   // chi²_t < chi² (mcsas.py:379)
+                    // chi²·Q of every candidate, should it be the accepted one: the same three numbers the decision
+                    // uses, one division, computed beside the comparison instead of behind the ballot
+                    const double Xc = S - num * num / den;
+                    unsigned long long amask = __ballot(acc_g);
+                    if (never_accept) amask = 0ull;                 // diagnostic: never accept
+                    const unsigned long long ovm = __ballot(cand && ovg);
+                    if (amask == 0ull) {
+                        if (ovm) overflow = 1;
+                        num_iter += cnt - start;
+                        break;
+                    }
+                    const int ga = __builtin_ctzll(amask);
+                    if (ovm & ((2ull << ga) - 1ull)) overflow = 1;
+                    const int acc_row = k0 + ga;
+                    // the steps behind the accepted one see ft + d_acc: h_k += Σ w d_acc d_k (read issued first)
+                    const double gk = Gs[(size_t)ga * W + (in ? g : 0)];
                     const int fresh = lstage[acc_row], freed = lslot[acc_row];
+                    SC = readlane_f64(SCt, ga); SIC = readlane_f64(SICt, ga); SCC = readlane_f64(SCCt, ga);
+                    X = readlane_f64(Xc, ga);
+                    MCSAS_IN_VGPR(SC); MCSAS_IN_VGPR(SIC); MCSAS_IN_VGPR(SCC); MCSAS_IN_VGPR(X);
+                    h += gk;
                     if (lane == 0) {
                         lslot[acc_row] = fresh; lstage[acc_row] = freed;      // slot swap: rows are never copied
                         lacc[num_acc_win] = acc_row;
+                        sacc[1 + 2 * nacc_sub] = freed; sacc[2 + 2 * nacc_sub] = fresh;
                     }
-                    ++num_acc_win; ++num_moves;
+                    ++nacc_sub; ++num_acc_win; ++num_moves;
                     touched = true;
-                    k_next = acc_row + 1; num_iter += ga + 1;
-                    if (!(X > cCrit * cnq)) live = false;
+                    num_iter += ga + 1 - start;
+                    start = ga + 1;
+                    if (!(X > cCrit * cnq)) { live = false; break; }
+                    if (start >= cnt) break;
                 }
-                if (lane == 0) { ctl[0] = k_next; ctl[1] = acc_row; ctl[2] = live ? 1 : 0; ctl[3] = g_next; }
+                cur.chi2 = X / cnq;                               // scale and background are only needed at the end of the attempt
+                if (lane == 0) { sacc[0] = nacc_sub; ctl[2] = live ? 1 : 0; }
+                __builtin_amdgcn_s_setprio(0);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            MCSAS_STAMP(s7);
-            __builtin_amdgcn_s_barrier();                                  // B2: decision published
-            MCSAS_STAMP(s8);
-            const int k_next = ctl[0], acc_row = ctl[1];
+            MCSAS_STAMP(s3);
+            __syncthreads();                                               // B2: decisions published
+            MCSAS_STAMP(s4);
             live = ctl[2] != 0;
-            G = ctl[3];
-            if (wave == 0) {
-                const int m_keep = (k + ((wave - (k & 7) + 8) & 7)) >> 3;
-                while (m_cur < m_keep) {
-                    ++m_cur;
-                    if (m_issue < my_rows && !dbg_noload) { issue_row(m_issue); ++m_issue; }
-                }
-            }
-            if (acc_row >= 0) {
-                // ft += d, w ft refreshed (mcsas.py:381-382): the accepted row sits in its owner's ring,
-                // landed before B1 and not refilled before the next B1
-                const double *dr = lds + ((size_t)(acc_row & 7) * RING + (size_t)((acc_row >> 3) & RMASK)) * qpad;
-                double dv[QPL];
+            const int nacc = sacc[0];
+            if (nacc > 0) {
+                // ---- ft <- (ft - old) + new for the accepted steps, in order (mcsas.py:367,381); one q per thread
 #pragma unroll
-                for (int j = 0; j < QPL; ++j) dv[j] = dr[lane + WAVE * j];
+                for (int x = 0; x < QT; ++x) {
+                    const int i = tid + T * x;
+                    if (i < qpad) {
+                        double f = lft[i];
+                        for (int n0 = 0; n0 < nacc; n0 += 4) {
+                            double o[4], nw[4];
 #pragma unroll
-                for (int j = 0; j < QPL; ++j) { ftr[j] += dv[j]; wftr[j] = wr[j] * ftr[j]; }
-                if (RING < 2 * (GMAX / 8)) {
-                    // a ring too shallow for a whole group refills at the top of the loop: nobody may
-                    // still be reading the accepted row then
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();                          // B3
+                            for (int u = 0; u < 4; ++u) {
+                                const int n = (n0 + u < nacc) ? n0 + u : nacc - 1;
+                                o[u] = cache[(size_t)sacc[1 + 2 * n] * qpad + i];
+                                nw[u] = cache[(size_t)sacc[2 + 2 * n] * qpad + i];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) if (n0 + u < nacc) f = (f - o[u]) + nw[u];
+                        }
+                        lft[i] = f; lwft[i] = wq[x] * f;
+                    }
                 }
+                __syncthreads();                                           // B3: ft complete; sacc may be rewritten
+                load_row_pairs<QPL>(lwft, lane, wftp);
             }
-            k = k_next;
 #ifdef MCSAS_STAMPS
-            MCSAS_STAMP(s9);
-            if (mine) { ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3; ph[4] += s5 - s4; ph[10] += 1; }
-            ph[5] += s6 - s5; ph[6] += s7 - s6; ph[7] += s8 - s7; ph[8] += s9 - s8; ph[9] += s9 - s0; ph[11] += 1;
+            MCSAS_STAMP(s5);
+            ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3; ph[4] += s5 - s4; ph[5] += 1; ph[6] += nacc;
 #endif
         }
         MCSAS_STAMP(sb2);
 #ifdef MCSAS_STAMPS
-        if (wave == 0 && lane == 0) for (int i = 0; i < 12; ++i) ch.dbg[i] += ph[i];
+        if (wave == 0 && lane == 0) for (int i = 0; i < 8; ++i) ch.dbg[i] += ph[i];
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // no DMA may outlive the ring
         if (wave == 0 && lane == 0) lacc[Kb] = num_acc_win;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __syncthreads();
         {   // write the window's slot tables back and store the accepted proposals (mcsas.py:381), all waves
             const int nacc = lacc[Kb];
             if (nacc > 0) {
@@ -547,17 +700,18 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     int r = ri0 + kk; if (r >= N) r -= N;
                     rset[(size_t)r * P + p] = pval[(size_t)kk * MCSAS_MAX_ACTIVE + p];
                 }
+                // park ft in HBM for the next tick
+                for (int i = tid; i < qpad; i += T) { gft[i] = lft[i]; gwft[i] = lwft[i]; }
             }
         }
         if (wave == 0) {
             if (touched) {
-                // re-sum the fit sums from ft so the incremental updates cannot drift; park ft in HBM
+                // re-sum the fit sums from ft so the incremental updates cannot drift
                 double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
-                    const double f = ftr[j], wf = wftr[j];
-                    s1 += wf; s2 += wf * f; s3 += wIr[j] * f;
-                    gft[lane + WAVE * j] = f; gwft[lane + WAVE * j] = wf;
+                    const double f = lft[lane + WAVE * j], wf = lwft[lane + WAVE * j];
+                    s1 += wf; s2 += wf * f; s3 += a.wI[lane + WAVE * j] * f;
                 }
                 wave_sum3(s1, s2, s3);
                 SC = s1; SCC = s2; SIC = s3;
@@ -579,7 +733,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
-                ft[j] = gft[lane + WAVE * j];
+                ft[j] = lft[lane + WAVE * j];
                 const double wf = a.w[lane + WAVE * j] * ft[j];
                 s1 += wf; s2 += wf * ft[j]; s3 += a.wI[lane + WAVE * j] * ft[j];
             }

@@ -2,9 +2,14 @@
 //
 // The device libm (ocml) sincos carries a Payne-Hanek large-argument path and costs ~110 executed
 // instructions per call; q·R on the hot path never exceeds ~1e5, so a 3-term FMA Cody-Waite
-// reduction + the fdlibm minimax kernels (|r| <= pi/4, error < 2^-58) is enough: ~34 instructions,
-// measured error <= 1.0 ulp over |x| < 2^20 (tests/test_fastmath.py compiles this header for the
-// host and checks it against long-double libm).  Larger arguments take the libm path.
+// reduction + the fdlibm minimax kernels (|r| <= pi/4, error < 2^-58) is enough: ~34 instructions.
+// Measured against extended-precision libm over |x| < 2^20 (tests/test_fastmath.py compiles this header
+// for the host: dense sweeps, the doubles next to every multiple of pi/2, the 2^20 hand-off):
+//   sincos_fast  <= 1.6 ulp relative (1.55 seen), <= 1.8e-16 absolute, next to multiples of pi/2 included;
+//   sincos_core  <= 1.8e-16 absolute everywhere, <= 1.6 ulp where |value| > 1e-9; closer to a multiple of
+//                pi/2 its dropped third reduction term (< 2e-27) shows as a relative error (absolute <= 2e-26);
+//   j1_fast / j1_core  <= 5e-16 absolute against scipy's Cephes j1;  div_fast <= 1 ulp;  rsqrt_fast <= 1.5 ulp.
+// Larger arguments take the libm path.
 #pragma once
 #include <math.h>
 

@@ -317,6 +317,16 @@ static int select_device(int device) {
     return MCSAS_OK;
 }
 
+// Every entry point that selects a device puts the calling thread's current device back on the way out: a
+// host that shares the HIP runtime (torch with RCCL in bench.py, the hosts of INTEGRATION.md) keeps its own.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // ------------------------------------------------------------------------------ plan
 struct mcsas_plan {
     mcsas_problem prob;
@@ -338,7 +348,7 @@ struct mcsas_plan {
     int mode = MCSAS_EXEC_WAVE;
     PipeArgs pipe{};
     PipeChain *d_chains = nullptr;
-    double *d_ft = nullptr, *d_wft = nullptr, *d_dwin = nullptr, *d_scal = nullptr, *d_pval = nullptr;
+    double *d_ft = nullptr, *d_wft = nullptr, *d_dwin = nullptr, *d_gwin = nullptr, *d_scal = nullptr, *d_pval = nullptr;
     int32_t *d_slot_of = nullptr, *d_stage = nullptr, *d_povf = nullptr;
     int32_t *h_done = nullptr;          // pinned + mapped: scan kernels count finished chains into it
     PipeArgs *d_pipeargs = nullptr;     // the argument block the tick kernels read (device copy)
@@ -387,7 +397,7 @@ extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     hipFree(pl->d_rset); hipFree(pl->d_cache); hipFree(pl->d_fit); hipFree(pl->d_replay); hipFree(pl->d_out);
     if (pl->h_stop) hipHostFree(pl->h_stop);
     if (pl->h_done) hipHostFree(pl->h_done);
-    hipFree(pl->d_pipeargs); hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_scal);
+    hipFree(pl->d_pipeargs); hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_gwin); hipFree(pl->d_scal);
     hipFree(pl->d_pval); hipFree(pl->d_slot_of); hipFree(pl->d_stage); hipFree(pl->d_povf);
     for (int i = 0; i < mcsas_plan::RING; ++i) {
         if (pl->evP[i]) hipEventDestroy(pl->evP[i]);
@@ -414,6 +424,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     if (rc) return rc;
     for (int c = 0; c < p->n_active; ++c)
         if (p->gen_kind[c] < 0 || p->gen_kind[c] > 3) return fail(MCSAS_EINVAL, "gen_kind[%d]=%d", c, p->gen_kind[c]);
+    DeviceGuard dev_guard;
     rc = select_device(p->device);
     if (rc) return rc;
 
@@ -443,6 +454,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
     const int tab_shared = table_doubles_host(p->model_id, margs.int_div), tab_row = rowtab_doubles_host(p->model_id, margs.int_div);
     const bool heavy_rows = tab_shared > 0 || margs.smear_nk > 0;
+    const int rpw_req = (p->reserved0 >> 8) & 15;          // tuning / diagnostics: rows per producer wave of the pipeline, 0 = automatic
 #define TABD(waves_per_block) (tab_shared + (waves_per_block) * tab_row)
     // execution mode (results do not depend on it)
     int mode = p->exec_mode;
@@ -456,7 +468,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             // one workgroup per chain up to ~400, one wavefront per chain beyond; rows that cost an integral
             // each keep the workgroup's seven producer waves per chain until the chains alone fill the SIMDs
             if (p->n_reps >= (heavy_rows ? 1024 : 448)) mode = MCSAS_EXEC_WAVE;
-            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
+            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
             else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
             else mode = MCSAS_EXEC_WAVE;
         }
@@ -496,7 +508,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: needs 2*window <= n_contrib and the window in LDS (nq=%d, n_contrib=%d, waves=%d)", p->nq, (int)N, waves); }
         cache_rows = (int)N + 2 * pl->wg.window;
     } else if (mode == MCSAS_EXEC_PIPELINE) {
-        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
+        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
         cache_rows = (int)N + 2 * pl->pipe.g.kb;
     }
     size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
@@ -553,6 +565,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         PCHK(hipMalloc(&pl->d_ft, sizeof(double) * R * qpad)); PCHK(hipMalloc(&pl->d_wft, sizeof(double) * R * qpad));
         PCHK(hipMalloc(&pl->d_slot_of, sizeof(int32_t) * R * N)); PCHK(hipMalloc(&pl->d_stage, sizeof(int32_t) * R * 2 * Kb));
         PCHK(hipMalloc(&pl->d_dwin, sizeof(double) * R * 2 * Kb * qpad));
+        PCHK(hipMalloc(&pl->d_gwin, sizeof(double) * R * 2 * Kb * pa.g.w));
         PCHK(hipMalloc(&pl->d_scal, sizeof(double) * R * 2 * Kb * 4));
         PCHK(hipMalloc(&pl->d_pval, sizeof(double) * R * 2 * Kb * MCSAS_MAX_ACTIVE));
         PCHK(hipMalloc(&pl->d_povf, sizeof(int32_t) * R * 2 * Kb));
@@ -565,7 +578,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             PCHK(hipEventCreateWithFlags(&pl->evS[i], hipEventDisableTiming));
         pa.c = a;
         pa.chains = pl->d_chains; pa.ft = pl->d_ft; pa.wft = pl->d_wft; pa.slot_of = pl->d_slot_of;
-        pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.scal = pl->d_scal; pa.pval = pl->d_pval;
+        pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.gwin = pl->d_gwin; pa.scal = pl->d_scal; pa.pval = pl->d_pval;
         pa.povf = pl->d_povf; pa.n_done = d_done; pa.tick = 0;
         pl->lds_bytes = std::max(pa.g.prod_lds, pa.g.scan_lds);
     }
@@ -600,8 +613,11 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
         HIPCHK(hipLaunchKernel(reset, dim3((R + 63) / 64), dim3(64), ka, 0, st));
     }
     // worst case: every attempt runs to max_iter
-    const long long win_per_attempt = (long long)((pl->prob.max_iter + Kb - 1) / Kb) + 3;
-    const long long max_ticks = std::min<long long>((long long)(pl->prob.max_retries + 1) * win_per_attempt + 4, 2000000000LL);
+    // (saturating: max_iter may be 2^62 and a product of two such numbers must not wrap to a negative budget)
+    const long long TICK_CAP = 2000000000LL;
+    const long long win_per_attempt = (long long)(pl->prob.max_iter / Kb) + 4;
+    const long long attempts = (long long)pl->prob.max_retries + 1;
+    const long long max_ticks = (win_per_attempt >= TICK_CAP / attempts) ? TICK_CAP : std::min(attempts * win_per_attempt + 4, TICK_CAP);
     const dim3 grid(R + R * pa.g.prod_blocks_y);
     long long t = -1;                                    // launch t = {SCAN(t), PROD(t+1)}
     for (; t < max_ticks; ++t) {
@@ -623,6 +639,7 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
 
 extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
     if (!pl) return fail(MCSAS_EINVAL, "null plan");
+    DeviceGuard dev_guard;
     HIPCHK(hipSetDevice(pl->dev));
     hipStream_t st = (hipStream_t)hip_stream;
     *pl->h_stop = (pl->prob.stop && *pl->prob.stop) ? 1 : 0;
@@ -662,6 +679,7 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
     if (!pl->launched) return fail(MCSAS_EINVAL, "plan was not launched");
     if (res && res->struct_size != sizeof(mcsas_result))
         return fail(MCSAS_EINVAL, "mcsas_result size %u, library expects %zu", res->struct_size, sizeof(mcsas_result));
+    DeviceGuard dev_guard;
     HIPCHK(hipSetDevice(pl->dev));
     // wait, forwarding the caller's stop word to the device-visible one (McSAS.stop, mcsas.py:357)
     for (;;) {
@@ -676,6 +694,9 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
     HIPCHK(hipEventElapsedTime(&ms, pl->ev0, pl->ev1));
     pl->last_ms = ms;
     const size_t R = pl->prob.n_reps, N = pl->prob.n_contrib, P = pl->prob.n_active, Q = pl->prob.nq, qpad = pl->args.qpad;
+    if (pl->mode == MCSAS_EXEC_PIPELINE && *(volatile int32_t *)pl->h_done < (int32_t)R)
+        return fail(MCSAS_EHIP, "pipeline: %d of %zu chains finished within the %d ticks that were launched",
+                    (int)*(volatile int32_t *)pl->h_done, R, pl->ticks_launched + 1);
     std::vector<ChainOut> ho(R);
     HIPCHK(hipMemcpy(ho.data(), pl->d_out, sizeof(ChainOut) * R, hipMemcpyDeviceToHost));
     int64_t steps = 0; int ovf = 0;
@@ -683,8 +704,8 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
     pl->last_steps = steps;
 #ifdef MCSAS_STAMPS
     {
-        static const char *names[20] = {"retire+issue", "vmcnt wait", "lds+fma", "wave_sum", "hbuf write", "B1 wait",
-                                        "decide(+idle)", "B2 wait", "ctl read+accept", "group total", "groups(mine)", "groups",
+        static const char *names[20] = {"rows+dot+reduce", "B1 wait", "decide", "B2 wait", "apply", "sub-windows", "accepted", "-",
+                                        "prod rows", "prod barrier", "prod gram", "prod blocks",
                                         "prologue", "epilogue", "window ticks", "block total", "gap between blocks (10ns)", "gaps", "in block (10ns)", "-"};
         for (size_t r = 0; r < R && r < 2; ++r) {
             fprintf(stderr, "[mcsas stamps] rep %zu (wave 0 cycles):", r);
@@ -771,6 +792,7 @@ extern "C" int mcsas_hip_model_calc(const mcsas_problem *p, const double *pset, 
     ModelArgs m;
     int rc = fill_model_args(p, &m);
     if (rc) return rc;
+    DeviceGuard dev_guard;
     rc = select_device(p->device);
     if (rc) return rc;
     const size_t Q = p->nq, P = p->n_active;
@@ -804,6 +826,7 @@ extern "C" int mcsas_hip_model_calc(const mcsas_problem *p, const double *pset, 
 extern "C" int mcsas_hip_bgfit(int32_t nq, const double *I, const double *sigma, const double *C, int32_t find_bg,
                                int32_t pos_bg, int32_t num_params, int32_t device, double out[4]) {
     if (nq < 1 || !I || !sigma || !C || !out) return fail(MCSAS_EINVAL, "bad argument");
+    DeviceGuard dev_guard;
     int rc = select_device(device);
     if (rc) return rc;
     DevBuf<double> dI, dS, dC, dO;
@@ -823,6 +846,7 @@ extern "C" int mcsas_hip_observability(const mcsas_problem *p, const double *con
     ModelArgs m;
     int rc = fill_model_args(p, &m);
     if (rc) return rc;
+    DeviceGuard dev_guard;
     rc = select_device(p->device);
     if (rc) return rc;
     const size_t Q = p->nq, P = p->n_active, N = p->n_contrib, R = p->n_reps;
@@ -858,6 +882,7 @@ extern "C" int mcsas_hip_histogram_prep(const mcsas_problem *p, const double *co
     ModelArgs m;
     int rc = fill_model_args(p, &m);
     if (rc) return rc;
+    DeviceGuard dev_guard;
     rc = select_device(p->device);
     if (rc) return rc;
     const size_t Q = p->nq, P = p->n_active, N = p->n_contrib, R = p->n_reps;
@@ -902,6 +927,7 @@ extern "C" int mcsas_hip_histogram_prep(const mcsas_problem *p, const double *co
 extern "C" int mcsas_hip_prepare_uncertainty(int32_t n, const double *intensity, const double *sigma_raw, double fu_min,
                                              int32_t device, double *sigma_out) {
     if (n < 1 || !intensity || !sigma_out) return fail(MCSAS_EINVAL, "bad argument");
+    DeviceGuard dev_guard;
     int rc = select_device(device);
     if (rc) return rc;
     DevBuf<double> dI, dS, dO;
@@ -919,6 +945,7 @@ extern "C" int mcsas_hip_rebin(int32_t n, const double *x, const double *f, cons
                                int32_t *n_out) {
     if (n < 1 || n_bin < 1 || n_bin > 1000000 || !x || !f || !fu || !edges || !x_out || !f_out || !fu_out || !n_out)
         return fail(MCSAS_EINVAL, "bad argument");
+    DeviceGuard dev_guard;
     int rc = select_device(device);
     if (rc) return rc;
     DevBuf<double> dx, df, du, de, bx, bf, bu;

@@ -74,7 +74,9 @@ class Parameter(object):
 
     def __init__(self, name, value, displayName=None, valueRange=None, **_ignored):
         self._name = name
-        self._valueRange = tuple(valueRange) if valueRange is not None else (-np.inf, np.inf)
+        self._valueRange = (-np.inf, np.inf)                  # a parameter declared without a range has none
+        if valueRange is not None:
+            self.setValueRange(valueRange)
         self._displayName = displayName or name
         self._value = value
 
@@ -93,7 +95,8 @@ class Parameter(object):
         return self._valueRange
 
     def setValueRange(self, newRange):
-        self._valueRange = (min(newRange), max(newRange))
+        # bases/algorithm/parameter.py:420-433: infinities are stored as +-1e200 ("as good as inf")
+        self._valueRange = (max(min(newRange), -1e200), min(max(newRange), 1e200))
 
     def min(self):
         return self._valueRange[0]

@@ -665,6 +665,131 @@ def gen_input_prep():
     np.savez_compressed(os.path.join(OUT, "g8_input_prep.npz"), **out)
 
 
+# ---------------------------------------------------------------- G9 (round 2: full-size replays)
+def model_truth_data(model, q_nm, truth, rs, noise=0.01):
+    """Synthetic curve from the REFERENCE's own model.calc on a known population, 1 % uncertainty."""
+    n = len(q_nm)
+    dtmp = sasdata(q_nm, np.ones(n), 0.01 * np.ones(n))
+    It = np.array(model.calc(dtmp, truth, 0.6666666).cumInt)
+    It = It / It.max() * 1e3
+    return sasdata(q_nm, It * (1 + noise * rs.normal(size=n)), noise * It)
+
+
+def kholodenko_file_data(nbin):
+    """What the reference's loader + input preparation give for testdata/sasfit_kho-1-10-1000.dat
+    (datafile/__init__.py:29-46, dataobj/dataobj.py:204-227,288-345): the file's uncertainty column is
+    -1, so the 1 % floor (fuMin) is what survives _prepareUncertainty; nbin = 0 keeps the 501 rows."""
+    d = loaddatafile("/root/reference/testdata/sasfit_kho-1-10-1000.dat").getDataObj()
+    d.config.nBin.setValue(nbin)
+    d._prepareUncertainty()
+    d._propagateMask()
+    d._reBin()
+    return d
+
+
+def gen_big_trajectories():
+    """Replays at the BASELINE.json shapes of configs 3 and 4 (and a mid-size Kholodenko chain on the
+    reference's own worm data file), so that the window / group / row-table paths of the GPU kernels
+    are pinned by the reference itself and not only against each other."""
+    rs = np.random.RandomState(2025)
+    # config 3 shape: isotropic cylinders, radius + aspect active, 512 q x 400 contributions, 2000 steps
+    q_nm = np.logspace(np.log10(0.01), np.log10(3.0), 512)
+    mc = CylindersIsotropic(); fix_intdiv(mc)
+    mc.radius.setActive(True); mc.aspect.setActive(True)
+    mc.radius.setActiveRange((1e-9, 1e-7)); mc.aspect.setActiveRange((0.5, 20.0))
+    truth = np.stack([rs.uniform(3e-9, 4e-8, 40), rs.uniform(1, 8, 40)], axis=1)
+    d = model_truth_data(mc, q_nm, truth, rs)
+    algo = new_algo(numContribs=400, numReps=1, maxIterations=2000, convergenceCriterion=1e-9)
+    algo.model = mc; algo.data = d
+    spec = dict(model="cyl_aspect", n_contrib=400, lo=[1e-9, 0.5], hi=[1e-7, 20.0], gen=[1, 1],
+                comp_exp=0.6666666, max_iter=2000, conv_crit=1e-9, sld=mc.sld(), int_div=100)
+    save_traj("g9_cyl_q512.npz", data_vectors(d), spec, run_mcfit(algo, 400, 3003))
+
+    # config 4 shape: core-shell ellipsoid, a / b / t active, 1024 q x 1000 contributions, 1500 steps
+    q_nm = np.logspace(np.log10(0.01), np.log10(3.0), 1024)
+    me = EllipsoidalCoreShell()
+    me.a.setActive(True); me.b.setActive(True); me.t.setActive(True)
+    me.a.setActiveRange((1e-9, 1e-7)); me.b.setActiveRange((2e-9, 2e-7)); me.t.setActiveRange((2e-10, 1e-8))
+    truth = np.stack([rs.uniform(3e-9, 3e-8, 40), rs.uniform(5e-9, 6e-8, 40), rs.uniform(5e-10, 5e-9, 40)], axis=1)
+    d = model_truth_data(me, q_nm, truth, rs)
+    algo = new_algo(numContribs=1000, numReps=1, maxIterations=1500, convergenceCriterion=1e-9)
+    algo.model = me; algo.data = d
+    spec = dict(model="ellcs", n_contrib=1000, lo=[1e-9, 2e-9, 2e-10], hi=[1e-7, 2e-7, 1e-8], gen=[1, 1, 1],
+                comp_exp=0.6666666, max_iter=1500, conv_crit=1e-9, eta_c=me.eta_c(), eta_s=me.eta_s(),
+                eta_sol=me.eta_sol(), int_div=100)
+    save_traj("g9_ellcs_q1024.npz", data_vectors(d), spec, run_mcfit(algo, 1000, 3004))
+
+    # Kholodenko on the reference's worm data, default 1 % floor, 64 log bins (some stay empty), 64
+    # contributions, 300 steps, the model's default active ranges (kholodenko.py:57-71)
+    d = kholodenko_file_data(64)
+    mk = Kholodenko()
+    n = 64
+    algo = new_algo(numContribs=n, numReps=1, maxIterations=300, convergenceCriterion=1e-9)
+    algo.model = mk; algo.data = d
+    spec = dict(model="kholodenko", n_contrib=n,
+                lo=[min(p.activeRange()) for p in mk.activeParams()],
+                hi=[max(p.activeRange()) for p in mk.activeParams()], gen=[1, 0, 0],
+                comp_exp=0.6666666, max_iter=300, conv_crit=1e-9)
+    save_traj("g9_kho_q64.npz", data_vectors(d), spec, run_mcfit(algo, n, 3006))
+
+
+def gen_kholodenko_config5(steps=300):
+    """BASELINE config 5 AS NAMED: the Kholodenko fit on testdata/sasfit_kho-1-10-1000.dat at 512 q x
+    600 contributions.  The file has 501 rows; the 512-point grid is the loader's (q, I) interpolated
+    log-log onto logspace(q_min, q_max, 512) with sigma = 1 % I.  QUADPACK makes this slow
+    (~0.8 ms per q per form factor: ~4 min for the initial set, ~0.8 s per step)."""
+    d0 = kholodenko_file_data(0)
+    q0 = np.array(d0.x0.unit.toDisplay(d0.q) if hasattr(d0.x0.unit, "toDisplay") else d0.q * 1e-9, dtype=float)
+    I0 = np.array(d0.f.binnedData, dtype=float)
+    assert len(q0) == 501 and np.all(np.diff(q0) > 0)
+    sig0 = np.array(d0.f.binnedDataU, dtype=float)
+    np.testing.assert_allclose(sig0, 0.01 * I0, rtol=1e-12)           # the 1 % floor is what the loader leaves
+    q_nm = np.logspace(np.log10(q0[0]), np.log10(q0[-1]), 512)
+    q_nm[0], q_nm[-1] = q0[0], q0[-1]
+    I = np.exp(np.interp(np.log(q_nm), np.log(q0), np.log(I0)))
+    d = sasdata(q_nm, I, 0.01 * I)
+    assert d.count == 512
+    mk = Kholodenko()
+    n = 600
+    algo = new_algo(numContribs=n, numReps=1, maxIterations=steps, convergenceCriterion=1e-9)
+    algo.model = mk; algo.data = d
+    spec = dict(model="kholodenko", n_contrib=n,
+                lo=[min(p.activeRange()) for p in mk.activeParams()],
+                hi=[max(p.activeRange()) for p in mk.activeParams()], gen=[1, 0, 0],
+                comp_exp=0.6666666, max_iter=steps, conv_crit=1e-9)
+    save_traj("g9_kho_q512.npz", data_vectors(d), spec, run_mcfit(algo, n, 3005),
+              extra=dict(file_q_nm=q0, file_I=I0))
+
+
+# ---------------------------------------------------------------- G10 (parameter declarations)
+def gen_param_declarations():
+    """What the reference's model classes declare (name, default, valueRange, activeRange, generator,
+    active flag; utils/parameter.py:577-743, models/*.py) and what McSAS.mcFit's generateParameters sees
+    — the mirror classes in mcsas_amd/scatteringmodels and setup_from_model are checked against this."""
+    import json
+    out = {}
+    classes = (Sphere, CylindersIsotropic, EllipsoidalCoreShell, Kholodenko, EllipsoidsIsotropic,
+               SphericalCoreShell, GaussianChain, LMADenseSphere)
+    for cls in classes:
+        m = cls()
+        plist = []
+        for p in m.params():
+            e = dict(name=p.name(), value=float(p()), fit=bool(hasattr(p, "isActive")))
+            vr = p.valueRange() if hasattr(p, "valueRange") else None
+            e["valueRange"] = [float(vr[0]), float(vr[1])] if vr is not None else None
+            if e["fit"]:
+                ar = p.activeRange()
+                e["active"] = bool(p.isActive())
+                e["activeRange"] = [float(min(ar)), float(max(ar))]
+                e["generator"] = p.generator().__name__
+            plist.append(e)
+        out[cls.__name__] = dict(shortName=cls.shortName, canSmear=bool(getattr(cls, "canSmear", False)),
+                                 params=plist, activeParams=[p.name() for p in m.activeParams()])
+    with open(os.path.join(OUT, "g10_param_decls.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("G10 written:", ", ".join(out))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     quiet_logging(None)
@@ -683,3 +808,10 @@ if __name__ == "__main__":
         gen_smearing()
     if "prep" in which:
         gen_input_prep()
+    # round 2 additions; "kho5" (~12 min of QUADPACK) only when asked for by name
+    if "big" in which or not sys.argv[1:]:
+        gen_big_trajectories()
+    if "decls" in which or not sys.argv[1:]:
+        gen_param_declarations()
+    if "kho5" in which:
+        gen_kholodenko_config5()

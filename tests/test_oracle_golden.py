@@ -85,7 +85,8 @@ def traj_setup(name):
 TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q512_fixed.npz",
         "g4_sphere_q100_nobg.npz", "g4_sphere_q100_posbg.npz", "g4_sphere_q100_frommin.npz",
         "g4_cyl_q40.npz", "g4_ellcs_q40.npz", "g4_kho_q24.npz", "g4_elliso_q40.npz", "g4_sphcs_q40.npz",
-        "g4_gausschain_q40.npz", "g4_lmasphere_q40.npz"]
+        "g4_gausschain_q40.npz", "g4_lmasphere_q40.npz",
+        "g9_cyl_q512.npz", "g9_ellcs_q1024.npz", "g9_kho_q64.npz", "g9_kho_q512.npz"]
 
 
 @pytest.mark.parametrize("name", TRAJ)
@@ -93,8 +94,13 @@ TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q5
 def test_g4_replay_trajectories(name, method):
     """Replaying the uniform stream the reference consumed reproduces its accept/reject decisions,
     final parameter set and chi² (leastsq: call-for-call restatement; closed: the kernels' fit)."""
-    if method == "leastsq" and name in ("g4_sphere_q100_converge.npz",):
-        pytest.skip("covered by the closed-form run (7.8k leastsq steps is slow)")
+    if method == "leastsq" and (name in ("g4_sphere_q100_converge.npz",) or name.startswith("g9_")):
+        pytest.skip("covered by the closed-form run (thousands of leastsq steps are slow)")
+    if name == "g9_kho_q512.npz" and not os.environ.get("MCSAS_SLOW_TESTS"):
+        pytest.skip("config 5 as named through the QUADPACK oracle takes ~10 min: set MCSAS_SLOW_TESTS=1 "
+                    "(run once per oracle change in the build container; result recorded in DESIGN.md)")
+    if not os.path.exists(os.path.join(G, name)):
+        pytest.skip("fixture %s not generated yet" % name)
     g, spec, st = traj_setup(name)
     res = O.mc_fit(spec, g["data_q"], g["data_I"], g["data_sigma"], g["data_f_limit"],
                    g["data_x0_limit"], st, O.ReplayStream(g["stream"]), method=method)
