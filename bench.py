@@ -1,18 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — MC accept/reject steps per second of the McSAS hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): Sphere model, synthetic 512 q-points x 400 contributions,
-50 repetitions per GPU, fixed Monte-Carlo budget per chain (convergenceCriterion = 0 so no chain
-leaves early; SURVEY §8d "throughput runs").  One bench "step" = one launch of all chains of the
-rank for `--mc-steps` MC iterations each, data and workspaces already resident in HBM.
-With --gpus N (one process per GPU, launched by torch.distributed.run) every rank runs its own
-50 reps (weak scaling) and one RCCL all-gather per step assembles the results.
+Headline workload (BASELINE.json configs[1]): Sphere model, synthetic 512 q-points x 400 contributions,
+50 repetitions per GPU, 20000 Monte-Carlo steps per chain per launch with convergenceCriterion = 0 (no chain
+leaves early; SURVEY 8d "throughput runs").  One bench "step" = `--launches-per-step` back-to-back launches of
+all chains of the rank (re-seeded each time, data and workspaces resident in HBM), so that the K timed steps
+cover seconds of steady-state clocks; per-launch device times (HIP events on the launch stream) are reported as
+min / median / max.
 
-Prints ONE JSON line; see the module-level keys `roofline` and `cpu_baseline`.
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--config 2|3|4|5]
+
+--gpus N > 1 without a torch.distributed environment: this process starts the N ranks itself
+(`python -m torch.distributed.run`, one process per GPU, 127.0.0.1 rendezvous) BEFORE anything touches the GPU,
+forwards their output and exits with their code; under an external launcher (WORLD_SIZE set) the world size must
+equal --gpus.  Weak scaling: every rank runs the config's per-GPU repetitions; strong scaling: the config's total
+repetitions (50 / 200 / 400 / 100) are sharded over the ranks (mcsas_amd.dist.shard_reps); chain id = global
+repetition index either way, and one all-gather (RCCL) per launch assembles the results.
+
+Prints ONE JSON line (rank 0); besides the contract's keys: `roofline` (SURVEY 8d byte model against HBM peak),
+`roofline_valu` (fp64 vector-issue view of the same launches), `launch_ms` (min / median / max), `configs` (short
+fixed-budget runs of configs 3-5 at their per-GPU repetition counts) and `cpu_baseline`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 Q, NCONTRIB, REPS_PER_GPU = 512, 400, 50
 HBM_PEAK = 8.0e12                     # B/s, MI355X_MICROARCH.md
-BYTES_PER_MC_STEP = 40 * Q            # read q, I, sigma, ft + write ft_test, fp64
+FP64_VECTOR_PEAK_INSTR = 256 * 4 * 2.4e9 / 4.0   # wave-instructions/s: 1024 SIMDs, one v_fma_f64 per 4 cycles (78.6 TFLOP/s)
 
 
 def synthetic_data(nq=Q, seed=20250101):
@@ -44,15 +57,55 @@ def synthetic_data(nq=Q, seed=20250101):
     return q, I, sigma
 
 
+def kholodenko_file_data():
+    """BASELINE config 5's data: testdata/sasfit_kho-1-10-1000.dat as the reference's loader prepares it (1 %
+    uncertainty floor), brought to 512 q-points; the vectors are the ones the reference itself was run on for the
+    fixture tests/golden/g9_kho_q512.npz (oracle/make_golden.py: gen_kholodenko_config5)."""
+    path = os.path.join(ROOT, "tests", "golden", "g9_kho_q512.npz")
+    g = np.load(path)
+    return np.array(g["data_q"]), np.array(g["data_I"]), np.array(g["data_sigma"])
+
+
+# BASELINE.json configs 2-5: model, data, contributions, repetitions (total over 8 GPUs / per GPU), instructions
+# per form-factor point (fp64 wave-instructions per 64 points, from the SQ_INSTS_VALU passes in profiles/)
+def workload(config):
+    import mcsas_amd
+    if config == 2:
+        q, I, s = synthetic_data(512)
+        m = mcsas_amd.Sphere(); m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
+        return dict(name="Sphere, synthetic 512 q-points x 400 contribs", model=m, q=q, I=I, sigma=s, n=400,
+                    reps_total=50, reps_gpu=50, K=1)
+    if config == 3:
+        q, I, s = synthetic_data(512)
+        m = mcsas_amd.CylindersIsotropic()
+        m.radius.setActive(True); m.aspect.setActive(True)
+        m.radius.setActiveRange((1e-9, 1e-7)); m.aspect.setActiveRange((0.5, 20.0))
+        return dict(name="Isotropic cylinders (radius + aspect, intDiv 100), synthetic 512 q x 400 contribs", model=m,
+                    q=q, I=I, sigma=s, n=400, reps_total=200, reps_gpu=25, K=100)
+    if config == 4:
+        q, I, s = synthetic_data(1024)
+        m = mcsas_amd.EllipsoidalCoreShell()
+        for name, rng in (("a", (1e-9, 1e-7)), ("b", (2e-9, 2e-7)), ("t", (2e-10, 1e-8))):
+            getattr(m, name).setActive(True); getattr(m, name).setActiveRange(rng)
+        return dict(name="Core-shell ellipsoid (a, b, t, intDiv 100), synthetic 1024 q x 1000 contribs", model=m,
+                    q=q, I=I, sigma=s, n=1000, reps_total=400, reps_gpu=50, K=200)
+    if config == 5:
+        q, I, s = kholodenko_file_data()
+        m = mcsas_amd.Kholodenko()
+        return dict(name="Kholodenko worm, testdata/sasfit_kho-1-10-1000.dat at 512 q x 600 contribs", model=m,
+                    q=q, I=I, sigma=s, n=600, reps_total=100, reps_gpu=13, K=1)
+    raise SystemExit("unknown --config %r" % config)
+
+
 def cpu_baseline(q, I, sigma, lo, hi, seconds_target=12.0):
     """The compiled CPU oracle (oracle/c/mcsas_oracle.c: plain-C restatement of mcFit with the closed-form
-    fit and cached rows, libm sin/cos) on every host core this process may use, one chain per thread at
-    a time, same workload shape, bounded sample.  The numpy restatement's single-core rate is reported
-    beside it (`numpy_port_1core`)."""
+    fit and cached rows, libm sin/cos) on the GPU's share of the host cores, one chain per thread at a time, same
+    workload shape, bounded sample; beside it the numpy restatement on the same number of cores, one chain per
+    process."""
     from oracle import mcsas_oracle as O
     from oracle import c_oracle
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(threads, int(os.environ.get("MCSAS_BENCH_CPU_THREADS", "16"))))   # one GPU's CPU share of the host
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(avail, int(os.environ.get("MCSAS_BENCH_CPU_THREADS", "16"))))   # one GPU's CPU share of the host
     c_oracle.load()
     probe = 20000
     t0 = time.time()
@@ -63,45 +116,124 @@ def cpu_baseline(q, I, sigma, lo, hi, seconds_target=12.0):
     r = c_oracle.analyse_sphere(q, I, sigma, lo, hi, NCONTRIB, threads, steps, 0.0, seed=1, threads=threads)
     dt = time.time() - t0
     out = {"value": float(r.num_iter.sum()) / dt, "unit": "MC steps/s", "cores": threads, "kind": "port",
+           "host_cores_total": os.cpu_count(), "host_cores_available": avail,
            "sample": "%d chains x %d MC steps (incl. %d-contribution init each), Sphere %dq x %d contribs, C oracle "
                      "(oracle/c, gcc -O2, libm), %d threads" % (threads, steps, NCONTRIB, Q, NCONTRIB, threads)}
-    spec = O.ModelSpec.make("sphere", ["radius"], [lo], [hi])
-    st = O.Settings(n_contrib=NCONTRIB, n_reps=1, max_iter=3000, conv_crit=0.0)
+    # the numpy restatement, one chain per process on the same number of cores
+    import multiprocessing as mp
+    nsteps = 2500
+    ctx = mp.get_context("spawn")          # this process holds a GPU context: no fork
     t0 = time.time()
-    rn = O.mc_fit(spec, q, I, sigma, [I.min(), I.max()], [q.min(), q.max()], st, O.PhiloxStream(1, 0), method="closed")
-    out["numpy_port_1core"] = rn.num_iter / (time.time() - t0)
+    with ctx.Pool(threads) as pool:
+        done = pool.map(_numpy_chain, [(q, I, sigma, lo, hi, nsteps, c) for c in range(threads)])
+    dtn = time.time() - t0
+    out["numpy_port"] = {"value": float(sum(done)) / dtn, "cores": threads,
+                         "sample": "%d processes x %d MC steps (incl. init), oracle/mcsas_oracle.py" % (threads, nsteps)}
     return out
+
+
+def _numpy_chain(args):
+    q, I, sigma, lo, hi, nsteps, chain = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import mcsas_oracle as O
+    spec = O.ModelSpec.make("sphere", ["radius"], [lo], [hi])
+    st = O.Settings(n_contrib=NCONTRIB, n_reps=1, max_iter=nsteps, conv_crit=0.0)
+    r = O.mc_fit(spec, q, I, sigma, [I.min(), I.max()], [q.min(), q.max()], st, O.PhiloxStream(1, chain), method="closed")
+    return r.num_iter
+
+
+# --------------------------------------------------------------------------------------------- multi-process
+def self_launch(args, argv):
+    """--gpus N > 1 with no launcher around us: become the launcher (nothing here touches the GPU)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
+class DryPlan(object):
+    """Stand-in for engine.Plan in the CPU tests of THIS FILE's multi-rank code path (tests/test_dist_gloo.py,
+    MCSAS_BENCH_DRY=1): no Monte Carlo, the per-repetition payload is a hash of (seed, global repetition index),
+    which is what makes a sharded run comparable with a 1-rank run repetition for repetition.  Never timed,
+    never reported as a measurement (`data` says "dry-run", `value` is null)."""
+
+    def __init__(self, n_contrib, n_active, nq, reps):
+        self.shape = (n_contrib, n_active, nq, reps)
+        self.seed, self.first = 0, 0
+        self.last_ms, self.total_steps = 1.0, 0
+        self.info = dict(exec_mode="dry", waves_per_chain=0, q_per_lane=0, window=0, launches=0, cached_rows=False)
+
+    def reseed(self, seed, first):
+        self.seed, self.first = seed, first
+
+    def launch(self):
+        pass
+
+    def fetch(self):
+        N, P, nq, R = self.shape
+
+        class Res(object):
+            pass
+        res = Res()
+        res.contribs = np.zeros((N, P, R)); res.fit = np.zeros((nq, R))
+        res.chisq = np.zeros(R); res.scaling = np.zeros(R); res.background = np.zeros(R)
+        for r in range(R):
+            rs = np.random.RandomState((self.seed * 1000003 + self.first + r) % (2**31 - 1))
+            res.contribs[:, :, r] = rs.rand(N, P); res.fit[:, r] = rs.rand(nq)
+            res.chisq[r], res.scaling[r], res.background[r] = rs.rand(3)
+        return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mc-steps", type=int, default=20000, help="MC iterations per chain per launch")
-    ap.add_argument("--reps", type=int, default=REPS_PER_GPU, help="repetitions (chains) per GPU")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE.json config 2..5 (headline: 2)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--launches-per-step", type=int, default=0,
+                    help="launches per bench step (0: enough for ~0.15 s per step on the headline config, 1 otherwise)")
+    ap.add_argument("--mc-steps", type=int, default=0, help="MC iterations per chain per launch (0: 20000 for config 2)")
+    ap.add_argument("--reps", type=int, default=0, help="repetitions (chains) per GPU, weak scaling (0: the config's)")
     ap.add_argument("--waves", type=int, default=0, help="waves per chain (0 = library default)")
     ap.add_argument("--mode", type=int, default=0, help="exec_mode: 0 auto, 1 wave, 2 workgroup, 3 pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true",
                     help="skip the untimed run-to-convergence (profiling: only the timed launches reach the profiler)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short runs of configs 3-5")
     ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic role ablation (invalid results)")
+    ap.add_argument("--dump", default="", help="rank 0: write the gathered arrays of the last launch to this .npz (tests)")
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if world_env is None and args.gpus > 1:
+        self_launch(args, sys.argv[1:])                      # does not return
+    rank = int(os.environ.get("RANK", "0")); world = int(world_env or "1")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d: refusing to report a different number of GPUs than asked for"
+                         % (args.gpus, world))
+
+    dry = os.environ.get("MCSAS_BENCH_DRY") == "1"
     import torch
     import mcsas_amd
     from mcsas_amd import engine, dist as mdist
 
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     # one process per GPU.  MCSAS_BENCH_BACKEND=gloo lets several ranks share one card for a dry run of
     # the multi-process path on a single-GPU box (results gathered through host memory)
     backend = os.environ.get("MCSAS_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
-    torch.cuda.set_device(dev_index)
+    dev_index = 0
+    if not dry:
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and ndev < world:
+            raise SystemExit("--gpus %d but only %d GPU(s) visible" % (world, ndev))
+        dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+        torch.cuda.set_device(dev_index)
     use_dist = world > 1
     if use_dist:
         import torch.distributed as tdist
@@ -110,93 +242,183 @@ def main():
         else:
             tdist.init_process_group(backend)
 
-    q, I, sigma = synthetic_data()
-    lo, hi = np.pi / q.max(), np.pi / q.min()
-    model = mcsas_amd.Sphere()
-    model.radius.setActiveRange((lo, hi))
-    n_total = args.reps * world
-    first = rank * args.reps
-    st = engine.Settings(n_contrib=NCONTRIB, n_reps=args.reps, max_iter=args.mc_steps, conv_crit=0.0,
-                         max_retries=0, seed=20250101, rep_offset=first, device=dev_index,
-                         waves_per_chain=args.waves, exec_mode=args.mode, debug_flags=args.debug_flags)
-    plan = engine.Plan(model.setup(), q, I, sigma, st)
+    wl = workload(args.config)
+    q, I, sigma, model, ncontrib = wl["q"], wl["I"], wl["sigma"], wl["model"], wl["n"]
+    if args.scaling == "weak":
+        reps = args.reps or wl["reps_gpu"]
+        n_total, first = reps * world, rank * reps
+    else:
+        n_total = args.reps * world if args.reps else wl["reps_total"]
+        if n_total < world:
+            raise SystemExit("strong scaling: %d repetitions cannot be sharded over %d ranks" % (n_total, world))
+        first, reps = mdist.shard_reps(n_total, world, rank)
+    mc_steps = args.mc_steps or {2: 20000, 3: 2000, 4: 1000, 5: 1000}[args.config]
+    lps = args.launches_per_step or (28 if args.config == 2 and not dry else 1)
+    setup = model.setup()
+    if dry:
+        plan = DryPlan(ncontrib, setup.n_active, len(q), reps)
+    else:
+        st = engine.Settings(n_contrib=ncontrib, n_reps=reps, max_iter=mc_steps, conv_crit=0.0,
+                             max_retries=0, seed=20250101, rep_offset=first, device=dev_index,
+                             waves_per_chain=args.waves, exec_mode=args.mode, debug_flags=args.debug_flags)
+        plan = engine.Plan(setup, q, I, sigma, st)
 
-    def one_step(seed):
+    launch_ms = []
+    gathered = {}
+
+    def one_launch(seed):
         plan.reseed(seed, first)
         plan.launch()
         res = plan.fetch()
-        if use_dist:
-            mdist.gather_results(dict(contribs=np.moveaxis(res.contribs, 2, 0), chisq=res.chisq[:, None],
-                                      scaling=res.scaling[:, None], background=res.background[:, None],
-                                      fit=res.fit.T), n_total)
+        launch_ms.append(plan.last_ms)
+        if use_dist or args.dump:
+            local = dict(contribs=np.moveaxis(res.contribs, 2, 0), chisq=res.chisq[:, None],
+                         scaling=res.scaling[:, None], background=res.background[:, None], fit=res.fit.T)
+            gathered.clear()
+            gathered.update(mdist.gather_results(local, n_total) if use_dist else {k: np.asarray(v) for k, v in local.items()})
         return res
 
     def barrier():
         if use_dist:
             tdist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
+    seed = 1000
     for w in range(args.warmup):
-        one_step(1000 + w)
+        for _ in range(lps):
+            one_launch(seed); seed += 1
     barrier()
+    del launch_ms[:]
     t0 = time.perf_counter()
-    kernel_ms, mc_steps, res = 0.0, 0, None
+    mc_total, res = 0, None
     for k in range(args.steps):
-        res = one_step(2000 + k)
-        kernel_ms += plan.last_ms
-        mc_steps += plan.total_steps
+        for _ in range(lps):
+            res = one_launch(seed); seed += 1
+            mc_total += plan.total_steps
     barrier()
     dt = time.perf_counter() - t0
+    ranks_seen = 1
     if use_dist:
-        t = torch.tensor([dt, float(mc_steps)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dev = "cuda" if backend == "nccl" and not dry else "cpu"
+        t = torch.tensor([dt, float(mc_total), 1.0], dtype=torch.float64, device=dev)
         tmax = t.clone(); tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
         tsum = t.clone(); tdist.all_reduce(tsum, op=tdist.ReduceOp.SUM)
-        dt, total_steps = float(tmax[0]), float(tsum[1])
+        dt, total_steps, ranks_seen = float(tmax[0]), float(tsum[1]), int(round(float(tsum[2])))
     else:
-        total_steps = float(mc_steps)
+        total_steps = float(mc_total)
 
     if rank == 0:
-        launch_s = kernel_ms * 1e-3 / args.steps
-        achieved = BYTES_PER_MC_STEP * (mc_steps / args.steps) / launch_s
-        # HBM-side bytes per MC step from the committed PMC passes of this same command
-        # (profiles/r01_pmc_summary.md: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); pipeline mode only
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
-        if plan.info["exec_mode"] == "pipeline" and os.path.exists(tj):
-            pm = json.load(open(tj))
-            traffic = (pm["fetch_bytes_per_mc_step"] + pm["write_bytes_per_mc_step"]) * (mc_steps / args.steps) / launch_s / 1e9
+        if args.dump:
+            np.savez(args.dump, **gathered)
+        lm = np.array(launch_ms) if launch_ms else np.zeros(1)
+        launch_s = float(lm.mean()) * 1e-3
+        steps_per_launch = mc_total / max(len(launch_ms), 1)
+        nq = len(q)
+        achieved = 40 * nq * steps_per_launch / max(launch_s, 1e-12)
+        info = plan.info
         out = {
-            "metric": "MC accept/reject steps/sec (whole node)", "value": total_steps / dt, "unit": "MC steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Sphere, synthetic %d q-points x %d contribs, %d reps/GPU, %d MC steps per chain per launch, convergenceCriterion=0"
-                                   % (Q, NCONTRIB, args.reps, args.mc_steps),
-                       "reps_total": n_total, **plan.info},
-            "final_chisq_median": float(np.median(res.chisq)),
-            "kernel_ms_per_launch": launch_s * 1e3,
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "note": "achieved = 40*Q B per MC step (SURVEY 8d streaming model, chain state actually stays on chip) x MC steps per launch / HIP-event time of the launch sequence"},
+            "metric": "MC accept/reject steps/sec (whole node)",
+            "value": None if dry else total_steps / dt, "unit": "MC steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "dry-run" if dry else ("synthetic" if args.config != 5 else "testdata/sasfit_kho-1-10-1000.dat (reference data file)"),
+            "config": {"workload": "%s, %d reps on this rank (%d in all), %d MC steps per chain per launch, convergenceCriterion=0"
+                                   % (wl["name"], reps, n_total, mc_steps),
+                       "baseline_config": args.config, "reps_total": n_total, "launches_per_step": lps,
+                       "ranks_seen": ranks_seen, **info},
+            "timed_region_s": dt,
+            "launch_ms": {"n": int(len(lm)), "min": float(lm.min()), "median": float(np.median(lm)), "max": float(lm.max()),
+                          "mean": float(lm.mean())},
         }
-        # outside the timed region: the same 50 repetitions run the way McSAS.analyse runs them
+        if not dry:
+            out["final_chisq_median"] = float(np.median(res.chisq))
+            # SURVEY 8d streaming model: 40*Q bytes per MC step against the HBM peak.  Chain state (q, I, sigma, ft)
+            # actually stays on chip, so this is an algorithmic figure; `traffic` is what the memory-side
+            # counters saw for the same command in the committed profile named in `traffic_source`.
+            traffic, source = None, None
+            tj = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            if args.config == 2 and info["exec_mode"] == "pipeline" and os.path.exists(tj):
+                pm = json.load(open(tj))
+                traffic = (pm["fetch_bytes_per_mc_step"] + pm["write_bytes_per_mc_step"]) * steps_per_launch / launch_s / 1e9
+                source = "from_profile: %s (commit %s)" % (os.path.relpath(tj, ROOT), pm.get("commit", "?"))
+            out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": source,
+                               "note": "achieved = 40*Q B per MC step (SURVEY 8d streaming model, no on-chip reuse credit) x MC steps "
+                                       "per launch / mean HIP-event time of a launch; q, I, sigma and ft stay on chip, so the figure may exceed the HBM peak"}
+            ij = os.path.join(ROOT, "profiles", "r02_valu_per_step.json")
+            if os.path.exists(ij):
+                pv = json.load(open(ij)).get(str(args.config))
+                if pv:
+                    rate = pv["valu_wave_instr_per_mc_step"] * steps_per_launch / launch_s
+                    out["roofline_valu"] = {"bound": "fp64 vector issue", "achieved": rate / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9,
+                                            "unit": "G wave-instr/s", "frac": rate / FP64_VECTOR_PEAK_INSTR,
+                                            "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
+                                            "source": "from_profile: profiles/r02_valu_per_step.json (SQ_INSTS_VALU pass, commit %s)" % pv.get("commit", "?")}
+        # outside the timed region: the same repetitions run the way McSAS.analyse runs them
         # (maxIterations = 1e5, maxRetries = 5) -> final chi² and steps to converge.  Criterion 2: with 1 %
         # noise on the synthetic curve 400 spheres plateau at chi² ~1.15 after 1e5 steps, so the default
         # criterion 1 is never met on this data set (every repetition then burns all 6 attempts)
         CRIT = 2.0
-        if not args.no_convergence_run:
-            stc = engine.Settings(n_contrib=NCONTRIB, n_reps=args.reps, max_iter=100000, conv_crit=CRIT, max_retries=5,
+        if not dry and not args.no_convergence_run and args.config == 2:
+            stc = engine.Settings(n_contrib=ncontrib, n_reps=reps, max_iter=100000, conv_crit=CRIT, max_retries=5,
                                   seed=20250101, rep_offset=first, device=dev_index, exec_mode=args.mode)
             t0 = time.perf_counter()
-            conv = engine.analyse(model.setup(), q, I, sigma, stc)
+            conv = engine.analyse(setup, q, I, sigma, stc)
             out["convergence_run"] = {"criterion": CRIT, "wall_s": time.perf_counter() - t0,
-                                      "converged": int(conv.converged.sum()), "reps": args.reps,
+                                      "converged": int(conv.converged.sum()), "reps": reps,
                                       "chisq_max": float(conv.chisq.max()), "chisq_mean": float(conv.chisq.mean()),
                                       "steps_mean": float(conv.num_iter.mean()), "attempts_max": int(conv.attempts.max())}
-        if not args.no_cpu_baseline and world == 1:           # the CPU baseline is timed at N = 1 only
+        if not dry and not args.no_configs and world == 1 and args.config == 2:
+            out["configs"] = other_configs(dev_index)
+        if not dry and not args.no_cpu_baseline and world == 1 and args.config == 2:   # the CPU baseline is timed at N = 1 only
+            lo, hi = np.pi / q.max(), np.pi / q.min()
             out["cpu_baseline"] = cpu_baseline(q, I, sigma, lo, hi)
         print(json.dumps(out))
     if use_dist:
         tdist.destroy_process_group()
+
+
+def other_configs(dev_index):
+    """Short fixed-budget runs of BASELINE configs 3-5 at their per-GPU repetition counts (200 / 400 / 100 repetitions
+    over 8 GPUs -> 25 / 50 / 13).  The chain initialisation (N form-factor rows per chain) is timed by a zero-step
+    launch of the same plan shape and reported beside the MC-step rate."""
+    from mcsas_amd import engine
+    out = {}
+    ij = os.path.join(ROOT, "profiles", "r02_valu_per_step.json")
+    prof = json.load(open(ij)) if os.path.exists(ij) else {}
+    for cfg, budget in ((3, 2000), (4, 1000), (5, 1000)):
+        wl = workload(cfg)
+        setup = wl["model"].setup()
+        times = {}
+        for label, steps in (("init", 0), ("run", budget)):
+            st = engine.Settings(n_contrib=wl["n"], n_reps=wl["reps_gpu"], max_iter=steps, conv_crit=0.0, max_retries=0,
+                                 seed=20250101, device=dev_index)
+            plan = engine.Plan(setup, wl["q"], wl["I"], wl["sigma"], st)
+            ms = []
+            for rep in range(3):
+                plan.reseed(77 + rep, 0); plan.launch(); res = plan.fetch(); ms.append(plan.last_ms)
+            times[label] = (min(ms), plan.total_steps, plan.info, float(np.median(res.chisq)))
+            plan.close()
+        t_init, t_run = times["init"][0], times["run"][0]
+        steps = times["run"][1]
+        rate = steps / max((t_run - t_init) * 1e-3, 1e-9)
+        pts = 2 * len(wl["q"]) * wl["K"]           # SURVEY 8d: T_step = 2 Q K form-factor points (new + old)
+        e = {"workload": "%s, %d reps (per-GPU share of %d), %d MC steps per chain" % (wl["name"], wl["reps_gpu"], wl["reps_total"], budget),
+             "value": rate, "unit": "MC steps/s", "init_ms": t_init, "run_ms": t_run, "exec_mode": times["run"][2]["exec_mode"],
+             "window": times["run"][2]["window"], "final_chisq_median": times["run"][3],
+             "ff_points_per_s_survey_model": rate * pts,
+             "roofline": {"bound": "hbm", "achieved": 40 * len(wl["q"]) * rate / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                          "frac": 40 * len(wl["q"]) * rate / HBM_PEAK, "traffic": None}}
+        pv = prof.get(str(cfg))
+        if pv:
+            r = pv["valu_wave_instr_per_mc_step"] * rate
+            e["roofline_valu"] = {"bound": "fp64 vector issue", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9,
+                                  "unit": "G wave-instr/s", "frac": r / FP64_VECTOR_PEAK_INSTR,
+                                  "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
+                                  "source": "from_profile: profiles/r02_valu_per_step.json (commit %s)" % pv.get("commit", "?")}
+        out[str(cfg)] = e
+    return out
 
 
 if __name__ == "__main__":

@@ -149,13 +149,21 @@ typedef struct mcsas_result {
     int64_t *draws;        /* [n_reps] uniforms consumed (replay bookkeeping); may be NULL */
 } mcsas_result;
 
-/* ---- one-shot: replaces McSAS.analyse()'s repetition loop (mcsas.py:214-262) ---------------- */
+/* ---- one-shot: replaces McSAS.analyse()'s repetition loop (mcsas.py:214-262) ----------------
+ * n_active == 0 (no active fit parameter, mcsas.py:198-201, 238-239, 322-323): the reference runs ONE
+ * repetition of ONE contribution and mcFit returns the model intensity at the fixed parameter values;
+ * here: fit[nq] = that intensity, chisq[0] = -1, scaling[0] = 1, background[0] = 0, num_iter[0] = 0 — the
+ * result arrays are then used as if n_contrib = n_reps = 1. */
 int mcsas_hip_analyse(const mcsas_problem *problem, mcsas_result *result);
 
 /* ---- resident plan: same work split so that inputs/workspaces live in HBM across runs ------- */
 typedef struct mcsas_plan mcsas_plan;
 int  mcsas_hip_plan_create(const mcsas_problem *problem, mcsas_plan **plan);
-/* enqueue all chains on `hip_stream` (a hipStream_t, NULL = default stream); asynchronous */
+/* enqueue all chains on `hip_stream` (a hipStream_t, NULL = default stream).  Wavefront / workgroup modes:
+ * one asynchronous kernel launch.  Pipeline mode: one launch per window of steps; the call stays ahead of the
+ * GPU by at most 64 launches and otherwise waits on an event (every 16 launches) while it forwards
+ * problem->stop and watches for the last chain to finish — it returns when everything is ENQUEUED, which for
+ * long runs is shortly before everything has run. */
 int  mcsas_hip_plan_launch(mcsas_plan *plan, void *hip_stream);
 /* wait for the launch (forwarding problem->stop meanwhile) and copy results out */
 int  mcsas_hip_plan_fetch(mcsas_plan *plan, mcsas_result *result);

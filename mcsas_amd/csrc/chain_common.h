@@ -82,7 +82,7 @@ struct DrawSource {
     const double *replay; int64_t replay_len; uint64_t seed; uint32_t chain;
     __device__ __forceinline__ double at(uint64_t idx, int &overflow) const {
         if (replay) {
-            if ((int64_t)idx < replay_len) return replay[idx];
+            if ((int64_t)idx < replay_len) return glb(replay)[idx];
             overflow = 1;
             return 0.5;
         }

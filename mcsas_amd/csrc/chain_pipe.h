@@ -27,6 +27,13 @@
 
 namespace mcsas {
 
+// Workgroup barrier for data handed over through LDS only: wait for this wave's LDS traffic, not for its global
+// loads and stores.  __syncthreads() also drains vmcnt — in the scan loop that would make every barrier wait
+// for the row batch that was prefetched just before it and for the stores of the accepted rows (a memory round
+// trip per barrier).  The "memory" clobbers keep the compiler from moving LDS accesses across (the barrier
+// builtin itself is IntrNoMem).
+#define PIPE_LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
 // Keep a wave-uniform double in a VGPR: the scan loop has far more uniform fp64 state than the 102
 // SGPRs can hold, and spilled SGPRs come back one v_readlane at a time on the critical path.
 #define MCSAS_IN_VGPR(x) asm volatile("" : "+v"(x))
@@ -59,7 +66,8 @@ struct PipeGeom {
     int32_t prod_blocks_y;        // producer blocks (= sub-windows) per chain and tick
     int32_t scan_waves;           // waves of a scan block
     int32_t qpl;
-    int32_t gram_off, pad;        // producer LDS: offset (doubles) of the Gram reduction buffer
+    int32_t gram_off;             // producer LDS: offset (doubles) of the Gram reduction buffer
+    int32_t recompute_new;        // 1: producers do not store the proposals' rows; the scan block re-evaluates the accepted ones
     uint64_t prod_lds, scan_lds;
 };
 
@@ -72,51 +80,110 @@ struct PipeArgs {
     int32_t *stage_slot;          // [R][2][kb]
     double *dwin;                 // [R][2][kb][qpad]   d rows of the window
     double *gwin;                 // [R][2][kb][w]      Gram blocks: row = step in the window, column = step in ITS sub-window
-    double *scal;                 // [R][2][kb][4]
+    double *scal;                 // [R][2][kb][4]   a = Σ w d, e = Σ wI d, g = Σ w d² of every step's row
+    unsigned char *pcon;          // [R][2][kb][PIPE_CON_BYTES]  the proposal's Contrib<M> (what its row evaluation needs)
     double *pval;                 // [R][2][kb][MAX_ACTIVE]
     int32_t *povf;                // [R][2][kb]
     int32_t *n_done;              // host-mapped: number of finished chains
     int32_t tick, pad;            // unused: the tick travels as its own kernel argument
 };
 
+// schedule records go through scalar global loads / stores (a struct copy out of an address-space-qualified
+// reference does not exist in C++)
+__device__ __forceinline__ PipeSnap load_snap(const PipeSnap *p) {
+    PipeSnap s;
+    s.attempt = glb(&p->attempt)[0]; s.t_init = glb(&p->t_init)[0]; s.alive = glb(&p->alive)[0]; s.pad = 0;
+    s.init_base = glb(&p->init_base)[0]; s.step_base = glb(&p->step_base)[0];
+    return s;
+}
+__device__ __forceinline__ void store_snap(PipeSnap *p, const PipeSnap &s) {
+    glb(&p->attempt)[0] = s.attempt; glb(&p->t_init)[0] = s.t_init; glb(&p->alive)[0] = s.alive; glb(&p->pad)[0] = 0;
+    glb(&p->init_base)[0] = s.init_base; glb(&p->step_base)[0] = s.step_base;
+}
+
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
 constexpr int PIPE_WAVES = PIPE_BLOCK / 64;
+constexpr int PIPE_CON_BYTES = 96;   // >= sizeof(Contrib<M>) of the models whose accepted rows the scan block re-evaluates
 constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
-static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, PipeGeom *g) {
+static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int recompute_req, PipeGeom *g) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
     const int qpad = qpl * 64;
-    // window: as many steps as 2*Kb <= N allows (a multiple of the 8 producer waves x rows per wave)
-    int rpw = 8;
+    // window: as many steps as 2*Kb <= N allows, Kb = (sub-windows) x (8 producer waves) x (rows per wave).
+    // Rows per wave set the sub-window W = 8 rpw: measured on config 2 (tools/sweep_flags.sh) W = 48 beats 64
+    // (Gram tiles per step fall from 10/64 to 6/48 and four producer blocks per chain instead of three fill
+    // the CUs the scan blocks leave free) and 32 (more scan sub-windows per tick): candidates in that order,
+    // the first one whose window is within 15 % of the largest wins.
+    // Rows that cost a numerical integration each (cylinders, ellipsoids, worm-like chains): one row per
+    // producer wave, so that a window is R*Kb waves for the 1024 SIMDs instead of R*Kb/8.
+    int rpw = 0, by = 0;
     if (rows_per_wave_req >= 1 && rows_per_wave_req <= 8) rpw = rows_per_wave_req;
-    // rows that cost a numerical integration each (cylinders, ellipsoids, worm-like chains): one row per
-    // producer wave, so that a window is R*Kb waves for the 1024 SIMDs instead of R*Kb/8
     else if (heavy_rows) rpw = 1;
-    while (rpw > 1 && 2 * 8 * rpw > n_contrib) --rpw;
-    if (2 * 8 * rpw > n_contrib) return 1;
-    int by = n_contrib / (2 * 8 * rpw);
-    if (by * 8 * rpw > 256) by = 256 / (8 * rpw);
+    if (rpw) {
+        while (rpw > 1 && 2 * 8 * rpw > n_contrib) --rpw;
+        if (2 * 8 * rpw > n_contrib) return 1;
+        by = n_contrib / (2 * 8 * rpw);
+        if (by * 8 * rpw > 256) by = 256 / (8 * rpw);
+    } else {
+        static const int order[6] = {6, 8, 4, 3, 2, 1};
+        int kbs[6], best_kb = 0;
+        for (int c = 0; c < 6; ++c) {
+            const int r = order[c];
+            int b = (2 * 8 * r > n_contrib) ? 0 : n_contrib / (2 * 8 * r);
+            if (b * 8 * r > 256) b = 256 / (8 * r);
+            kbs[c] = b * 8 * r;
+            if (kbs[c] > best_kb) best_kb = kbs[c];
+        }
+        if (best_kb == 0) return 1;
+        for (int c = 0; c < 6 && !rpw; ++c)                   // a window within 15 % of the largest is as good
+            if (kbs[c] > 0 && 20 * kbs[c] >= 17 * best_kb) { rpw = order[c]; by = kbs[c] / (8 * rpw); }
+    }
     g->kb = by * 8 * rpw; g->qpl = qpl; g->w = 8 * rpw;
+    g->recompute_new = (heavy_rows || !recompute_req) ? 0 : 1;
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
     g->gram_off = 4 * qpad + tab_doubles;
     g->prod_lds = sizeof(double) * ((size_t)g->gram_off + (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256);
     g->scan_waves = PIPE_WAVES;
     // scan block LDS: two Gram blocks (double buffer), ft and w*ft, the window's scalars, h of the sub-window,
-    // flags / slot tables / accepted lists
-    g->scan_lds = sizeof(double) * (2 * (size_t)g->w * g->w + 2 * (size_t)qpad + (size_t)g->kb * 4 + 64)
-                + sizeof(int32_t) * (4 * (size_t)g->kb + 1 + 2 * 64 + 4 + 8) + 64;
+    // h, a, e, g of the sub-window, flags / slot tables / accepted lists
+    g->scan_lds = sizeof(double) * (2 * (size_t)g->w * g->w + 2 * (size_t)qpad + (size_t)g->kb * (PIPE_CON_BYTES / 8 + 4) + 64)
+                + sizeof(int32_t) * (4 * (size_t)g->kb + 1 + 3 * 64 + 4 + 8) + 64;
     if (g->scan_lds > 160 * 1024 || g->prod_lds > 160 * 1024) return 1;
     return 0;
+}
+
+// Models whose accepted rows the scan block re-evaluates itself (a few hundred instructions per row) instead of
+// having every proposal's row written to HBM by the producers (4 KB per step, 94 % of them rejected): the ones
+// without an orientation / contour integral.  Same function, same inputs as RowEval -> the same bits.
+constexpr bool pipe_light_model(int m) {
+    return m == MCSAS_MODEL_SPHERE || m == MCSAS_MODEL_SPH_CS || m == MCSAS_MODEL_GAUSS_CHAIN || m == MCSAS_MODEL_LMA_SPHERE;
+}
+template <int M>
+__device__ __forceinline__ double pipe_point_intensity(const Contrib<M> &c, double q, double q3inv) {
+    if constexpr (M == MCSAS_MODEL_SPHERE) return c.fast ? c.intensity_fast(q, q3inv) : c.intensity(q, nullptr);
+    else return c.intensity(q, nullptr);
 }
 
 // one row of the window buffers as every kernel here holds it in registers: 16-byte loads, lane l and
 // register pair c <-> q = 128 c + 2 l + {0, 1}  (QPL = 1: one 8-byte load, q = l)
 template <int QPL>
-__device__ __forceinline__ void load_row_pairs(const double *row, int lane, double (&r)[QPL]) {
+__device__ __forceinline__ void load_row_pairs(const MCSAS_GLOBAL double *row, int lane, double (&r)[QPL]) {
+    if constexpr (QPL >= 2) {
+#pragma unroll
+        for (int c = 0; c < QPL / 2; ++c) {
+            const v2f64 v = *(const MCSAS_GLOBAL v2f64 *)(row + 128 * c + 2 * lane);
+            r[2 * c] = v.x; r[2 * c + 1] = v.y;
+        }
+    } else {
+        r[0] = row[lane];
+    }
+}
+template <int QPL>
+__device__ __forceinline__ void load_row_pairs_lds(const double *row, int lane, double (&r)[QPL]) {
     if constexpr (QPL >= 2) {
 #pragma unroll
         for (int c = 0; c < QPL / 2; ++c) {
@@ -139,89 +206,91 @@ __device__ __forceinline__ void load_row_pairs(const double *row, int lane, doub
 // contiguous bytes, so a 128-byte line is consumed by two consecutive loads instead of lingering in L1.
 // The eight partial tiles are then summed in wave order through LDS (deterministic) and written to
 // gout[a][k], a, k < W.
-template <int QPL>
-__device__ __forceinline__ void pipe_prod_gram(const double *drows, int qpad, int W, int nvalid, const double *lw,
-                                               double *gred, double *gout) {
+template <int QPL, int T>                                     // T = 16-row groups of the sub-window (1..4), compile time: straight-line MFMA code
+__device__ __forceinline__ void pipe_prod_gram_t(const MCSAS_GLOBAL double *drows, int qpad, int W, int nvalid, const double *lw,
+                                                 double *gred, MCSAS_GLOBAL double *gout) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kk = lane >> 4;
-    const int T = (W + 15) >> 4;                              // 16-row groups (<= 4)
+    constexpr int NT = T * (T + 1) / 2;                       // upper-triangular tiles (gi <= gj), row-major
     const int qs = wave * (8 * QPL) + kk * 2;
-    v4f64 acc[10];
+    v4f64 acc[NT];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) acc[i] = (v4f64){0., 0., 0., 0.};
-    const double *rowp[4];
-    bool rowok[4];
+    for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0., 0., 0., 0.};
+    const MCSAS_GLOBAL double *rowp[T];
+    bool rowok[T];
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
+    for (int gi = 0; gi < T; ++gi) {
         const int rr = 16 * gi + m;
-        rowok[gi] = gi < T && rr < nvalid;
+        rowok[gi] = rr < nvalid;
         rowp[gi] = drows + (size_t)(rowok[gi] ? rr : 0) * qpad + qs;
     }
     // loads run one step-pair ahead of the MFMAs that consume them (an L2 round trip per step-pair otherwise)
-    v2f64 nxt[4], wnx;
-    auto fetch = [&](int s, v2f64 (&dst)[4], v2f64 &wdst) {
+    v2f64 nxt[T], wnx;
+    auto fetch = [&](int s, v2f64 (&dst)[T], v2f64 &wdst) {
         wdst = *reinterpret_cast<const v2f64 *>(lw + qs + 4 * s);
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-            dst[gi] = (v2f64){0., 0.};
-            if (gi < T) dst[gi] = *reinterpret_cast<const v2f64 *>(rowp[gi] + 4 * s);
-        }
+        for (int gi = 0; gi < T; ++gi) dst[gi] = *(const MCSAS_GLOBAL v2f64 *)(rowp[gi] + 4 * s);
     };
     fetch(0, nxt, wnx);
 #pragma unroll
     for (int s = 0; s < 2 * QPL; s += 2) {
-        v2f64 av[4], bv[4];
+        v2f64 av[T], bv[T];
         const v2f64 wv = wnx;
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) av[gi] = rowok[gi] ? nxt[gi] : (v2f64){0., 0.};
+        for (int gi = 0; gi < T; ++gi) av[gi] = rowok[gi] ? nxt[gi] : (v2f64){0., 0.};
         if (s + 2 < 2 * QPL) fetch(s + 2, nxt, wnx);
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) bv[gi] = av[gi] * wv;
+        for (int gi = 0; gi < T; ++gi) bv[gi] = av[gi] * wv;
         int ti = 0;
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi)
+        for (int gi = 0; gi < T; ++gi)
 #pragma unroll
-            for (int gj = gi; gj < 4; ++gj) {
-                if (gj < T) {
-                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].x, bv[gj].x, acc[ti], 0, 0, 0);
-                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].y, bv[gj].y, acc[ti], 0, 0, 0);
-                }
+            for (int gj = gi; gj < T; ++gj) {
+                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].x, bv[gj].x, acc[ti], 0, 0, 0);
+                acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].y, bv[gj].y, acc[ti], 0, 0, 0);
                 ++ti;
             }
     }
     // cross-wave sum, PIPE_GRAM_TILES_PER_ROUND tiles per round
     constexpr int TPR = PIPE_GRAM_TILES_PER_ROUND;
 #pragma unroll
-    for (int r0 = 0; r0 < 10; r0 += TPR) {
-        bool any = false;                                     // does this round hold a tile with gj < T ?
-        {
-            int ti = 0;
-#pragma unroll
-            for (int gi = 0; gi < 4; ++gi)
-#pragma unroll
-                for (int gj = gi; gj < 4; ++gj) { if (ti >= r0 && ti < r0 + TPR && gj < T) any = true; ++ti; }
-        }
-        if (!any) continue;                                   // uniform for the block
+    for (int r0 = 0; r0 < NT; r0 += TPR) {
 #pragma unroll
         for (int u = 0; u < TPR; ++u)
+            if (r0 + u < NT) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gred[((size_t)(wave * TPR + u) * 4 + r) * 64 + lane] = acc[r0 + u][r];
-        __syncthreads();
+                for (int r = 0; r < 4; ++r) gred[((size_t)(wave * TPR + u) * 4 + r) * 64 + lane] = acc[r0 + u < NT ? r0 + u : 0][r];
+            }
+        PIPE_LDS_BARRIER();
         {
             const int u = tid >> 8, idx = tid & 255;          // 512 threads <-> TPR (= 2) tiles x 256 elements
-            double sum = 0.;
+            const int tsel = r0 + u;
+            if (tsel < NT) {
+                double sum = 0.;
 #pragma unroll
-            for (int v = 0; v < PIPE_WAVES; ++v) sum += gred[(size_t)(v * TPR + u) * 256 + idx];
-            int ti = 0, tgi = -1, tgj = -1;
+                for (int v = 0; v < PIPE_WAVES; ++v) sum += gred[(size_t)(v * TPR + u) * 256 + idx];
+                int ti = 0, tgi = 0, tgj = 0;
 #pragma unroll
-            for (int gi = 0; gi < 4; ++gi)
+                for (int gi = 0; gi < T; ++gi)
 #pragma unroll
-                for (int gj = gi; gj < 4; ++gj) { if (ti == r0 + u) { tgi = gi; tgj = gj; } ++ti; }
-            const int i = 4 * (idx >> 6) + ((idx & 63) >> 4), j = idx & 15;
-            const int ar = 16 * tgi + i, kc = 16 * tgj + j;
-            if (tgi >= 0 && tgj < T && ar < W && kc < W) gout[(size_t)ar * W + kc] = sum;
+                    for (int gj = gi; gj < T; ++gj) { if (ti == tsel) { tgi = gi; tgj = gj; } ++ti; }
+                const int i = 4 * (idx >> 6) + ((idx & 63) >> 4), j = idx & 15;
+                const int ar = 16 * tgi + i, kc = 16 * tgj + j;
+                if (ar < W && kc < W) gout[(size_t)ar * W + kc] = sum;
+            }
         }
-        __syncthreads();
+        if (r0 + TPR < NT) PIPE_LDS_BARRIER();
+    }
+}
+
+template <int QPL>
+__device__ __forceinline__ void pipe_prod_gram(const MCSAS_GLOBAL double *drows, int qpad, int W, int nvalid, const double *lw,
+                                               double *gred, MCSAS_GLOBAL double *gout) {
+    switch ((W + 15) >> 4) {                                   // uniform for the launch
+        case 1: pipe_prod_gram_t<QPL, 1>(drows, qpad, W, nvalid, lw, gred, gout); break;
+        case 2: pipe_prod_gram_t<QPL, 2>(drows, qpad, W, nvalid, lw, gred, gout); break;
+        case 3: pipe_prod_gram_t<QPL, 3>(drows, qpad, W, nvalid, lw, gred, gout); break;
+        default: pipe_prod_gram_t<QPL, 4>(drows, qpad, W, nvalid, lw, gred, gout); break;
     }
 }
 
@@ -231,23 +300,23 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int WPB = PIPE_BLOCK / 64;
     const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb;
-    const PipeSnap sn = pa.chains[rep].snap[t & 1];
+    const PipeSnap sn = load_snap(&pa.chains[rep].snap[t & 1]);
     if (!sn.alive || t < sn.t_init) return;
 
     double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
     for (int i = tid; i < qpad; i += PIPE_BLOCK) {
-        const double qq = a.q[i];
-        lq[i] = qq; lw[i] = a.w[i]; lwI[i] = a.wI[i]; lq3[i] = 1.0 / (qq * qq * qq);
+        const double qq = glb(a.q)[i];
+        lq[i] = qq; lw[i] = glb(a.w)[i]; lwI[i] = glb(a.wI)[i]; lq3[i] = 1.0 / (qq * qq * qq);
     }
     Contrib<M>::fill_table(a.model, tab, tid, PIPE_BLOCK);
     __syncthreads();
     const QTables qt = make_qtables<M>(a.model, lq, lq3, tab);
-    double *rset = a.rset + (size_t)rep * N * P;
-    double *cache = a.cache + (size_t)rep * a.cache_rows * qpad;
+    auto rset = glb(a.rset) + (size_t)rep * N * P;
+    auto cache = glb(a.cache) + (size_t)rep * a.cache_rows * qpad;
     const DrawSource src{a.replay ? a.replay + (size_t)rep * a.replay_len : nullptr, a.replay_len, a.seed,
                          (uint32_t)(a.rep_offset + rep)};
-    int32_t *slot_of = pa.slot_of + (size_t)rep * N;
-    int32_t *stage = pa.stage_slot + (size_t)rep * 2 * Kb;
+    auto slot_of = glb(pa.slot_of) + (size_t)rep * N;
+    auto stage = glb(pa.stage_slot) + (size_t)rep * 2 * Kb;
     const int gw = by * WPB + wave, nw = gy * WPB;          // this wave's index among the chain's producer waves
 
     if (t == sn.t_init) {
@@ -312,10 +381,12 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     }
     Contrib<M> prop;
     prop.prepare(a.model, prow);
-    double *dwin = pa.dwin + ((size_t)rep * 2 + buf) * Kb * qpad;
-    double *scal = pa.scal + ((size_t)rep * 2 + buf) * Kb * 4;
-    double *pval = pa.pval + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
-    int32_t *povf = pa.povf + ((size_t)rep * 2 + buf) * Kb;
+    auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
+    auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
+    auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
+    auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
+    unsigned char *pcon = pa.pcon + ((size_t)rep * 2 + buf) * Kb * PIPE_CON_BYTES;
+    const bool keep_new = !(pipe_light_model(M) && pa.g.recompute_new);
     int ri = (int)(s0 % N);
     // row slots of all my rows in one round trip (lane i <-> my row i): the row loop below then starts its loads
     // of `old` without waiting for a dependent index load per row
@@ -330,18 +401,21 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
         const int bl = __builtin_amdgcn_readfirstlane(i);
         const Contrib<M> cnew = prop.bcast(bl);
         const int oslot = __builtin_amdgcn_readlane(my_oslot, bl), sslot = __builtin_amdgcn_readlane(my_sslot, bl);
-        const double *orow = cache + (size_t)oslot * qpad + lane;
-        double *nrow = cache + (size_t)sslot * qpad + lane;
-        double *dr = dwin + (size_t)k * qpad + lane;
+        const auto orow = cache + (size_t)oslot * qpad + lane;
+        const auto nrow = cache + (size_t)sslot * qpad + lane;
+        const auto dr = dwin + (size_t)k * qpad + lane;
         double d[QPL], nwv[QPL];
 #pragma unroll
         for (int j = 0; j < QPL; ++j) d[j] = orow[WAVE * j];
         RowEval<M, QPL>::run(cnew, qt, lane, nwv);
+        // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  (Taking the
+        // sums in the scan block's pass over the row instead was measured: its single h pass is the serial part of a
+        // tick, 5x the dot-product work there cost 8 us per tick, here it is spread over every CU.)
         double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
         for (int j = 0; j < QPL; ++j) {
             const int iq = lane + WAVE * j;
-            nrow[WAVE * j] = nwv[j];
+            if (keep_new) nrow[WAVE * j] = nwv[j];
             d[j] = nwv[j] - d[j];
             dr[WAVE * j] = d[j];
             const double wd = lw[iq] * d[j];
@@ -355,6 +429,10 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
                 const double v = readlane_f64(prow[p], bl);
                 if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
             }
+        if constexpr (pipe_light_model(M)) {
+            static_assert(sizeof(Contrib<M>) <= PIPE_CON_BYTES, "PIPE_CON_BYTES too small for this model");
+            if (!keep_new && lane == 0) *reinterpret_cast<Contrib<M> *>(pcon + (size_t)k * PIPE_CON_BYTES) = cnew;
+        }
         const int ov = __builtin_amdgcn_readlane(pov, bl);
         if (lane == 0) povf[k] = ov;
         ri = (ri + 1 == N) ? 0 : ri + 1;
@@ -371,7 +449,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
         const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
         if (nvalid > 1)
             pipe_prod_gram<QPL>(dwin + (size_t)by * W * qpad, qpad, W, nvalid, lw, lds + pa.g.gram_off,
-                                pa.gwin + (((size_t)rep * 2 + buf) * Kb + (size_t)by * W) * W);
+                                glb(pa.gwin) + (((size_t)rep * 2 + buf) * Kb + (size_t)by * W) * W);
     }
 #ifdef MCSAS_STAMPS
     MCSAS_STAMP(pp3);
@@ -387,7 +465,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
 
 // ------------------------------------------------------------------------------------ scanner
 // LDS: two Gram blocks, ft and w*ft, the window's scalars, h of the current sub-window, flags and slot tables
-template <int QPL>
+template <int M, int QPL>
 __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds, int rep, int t, int stop_now) {
     static_assert(PIPE_GRAM_TILES_PER_ROUND * 256 == PIPE_BLOCK, "Gram reduction maps one thread to one tile element");
     const ChainArgs &a = pa.c;
@@ -395,36 +473,39 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb, W = pa.g.w, RPW = pa.g.rows_per_wave;
     constexpr int T = PIPE_BLOCK;
-    PipeChain &ch = pa.chains[rep];
+    MCSAS_GLOBAL PipeChain &ch = glb(pa.chains)[rep];
     if (ch.done) return;                                      // uniform for the block
     MCSAS_STAMP_DECL(sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0);
     MCSAS_STAMP(sb0);
 #ifdef MCSAS_STAMPS
     const uint64_t wc0 = wall_clock64();
 #endif
-    const PipeSnap sn = ch.snap[(t + 1) & 1];                 // the record in force for tick t (written at t-1; host for t = 0)
+    const PipeSnap sn = load_snap(&pa.chains[rep].snap[(t + 1) & 1]);   // the record in force for tick t (written at t-1; host for t = 0)
 
     double *Gl = lds;                                         // [2][W*W] Gram block of the current / next sub-window
     double *lft = Gl + 2 * (size_t)W * W;                     // [qpad] ft, q-indexed
     double *lwft = lft + qpad;                                // [qpad] w * ft
-    double *ssub = lwft + qpad;                               // [Kb][4] scalars of the whole window
-    double *hbuf = ssub + (size_t)Kb * 4;                     // [64] h of the current sub-window, by step offset
-    int32_t *osub = reinterpret_cast<int32_t *>(hbuf + 64);   // [Kb] replay-overflow flags
+    double *lcon = lwft + qpad;                               // [Kb][PIPE_CON_BYTES / 8] the window's proposals as Contrib<M> records
+    double *ssub = lcon + (size_t)Kb * (PIPE_CON_BYTES / 8);  // [Kb][4] a, e, g of every step of the window
+    double *hsub = ssub + (size_t)Kb * 4;                     // [64] h of the current sub-window, by step offset
+    int32_t *osub = reinterpret_cast<int32_t *>(hsub + 64);   // [Kb] replay-overflow flags
     int32_t *lstage = osub + Kb, *lslot = lstage + Kb;        // [Kb] spare row slot of step k / row slot of its contribution
     int32_t *lacc = lslot + Kb;                               // [Kb + 1] accepted steps of this window, count in lacc[Kb]
-    int32_t *sacc = lacc + Kb + 1;                            // [1 + 2*64] this sub-window: count, then (old slot, new slot) per accepted step
-    int32_t *ctl = sacc + 1 + 2 * 64;                         // [4]: [2] = live
-    double *gft = pa.ft + (size_t)rep * qpad, *gwft = pa.wft + (size_t)rep * qpad;
-    double *rset = a.rset + (size_t)rep * N * P;
-    double *cache = a.cache + (size_t)rep * a.cache_rows * qpad;
+    int32_t *sacc = lacc + Kb + 1;                            // [1 + 3*64] this sub-window: count, then (old slot, new slot, step) per accepted step
+    int32_t *ctl = sacc + 1 + 3 * 64;                         // [4]: [2] = live
+    auto gft = glb(pa.ft) + (size_t)rep * qpad, gwft = glb(pa.wft) + (size_t)rep * qpad;
+    auto rset = glb(a.rset) + (size_t)rep * N * P;
+    auto cache = glb(a.cache) + (size_t)rep * a.cache_rows * qpad;
     const int buf = t & 1;
-    const double *dwin = pa.dwin + ((size_t)rep * 2 + buf) * Kb * qpad;
-    const double *gwin = pa.gwin + ((size_t)rep * 2 + buf) * Kb * W;
-    const double *scal = pa.scal + ((size_t)rep * 2 + buf) * Kb * 4;
-    const double *pval = pa.pval + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
-    const int32_t *povf = pa.povf + ((size_t)rep * 2 + buf) * Kb;
-    int32_t *slot_of = pa.slot_of + (size_t)rep * N;
-    int32_t *stage = pa.stage_slot + ((size_t)rep * 2 + buf) * Kb;
+    const auto dwin = glb((const double *)pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
+    const auto gwin = glb((const double *)pa.gwin) + ((size_t)rep * 2 + buf) * Kb * W;
+    const auto scal = glb((const double *)pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
+    const unsigned char *pcon = pa.pcon + ((size_t)rep * 2 + buf) * Kb * PIPE_CON_BYTES;
+    const auto pval = glb((const double *)pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
+    const auto povf = glb((const int32_t *)pa.povf) + ((size_t)rep * 2 + buf) * Kb;
+    auto slot_of = glb(pa.slot_of) + (size_t)rep * N;
+    auto stage = glb(pa.stage_slot) + ((size_t)rep * 2 + buf) * Kb;
+    const auto gw_ = glb(a.w), gwI_ = glb(a.wI), gI_ = glb(a.I);
     const double nqd = (double)a.nq;
 
     // scanner-side chain state (meaningful in wave 0)
@@ -448,8 +529,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
-                const double wf = a.w[lane + WAVE * j] * ft[j];
-                s1 += wf; s2 += wf * ft[j]; s3 += a.wI[lane + WAVE * j] * ft[j];
+                const double wf = gw_[lane + WAVE * j] * ft[j];
+                s1 += wf; s2 += wf * ft[j]; s3 += gwI_[lane + WAVE * j] * ft[j];
                 gft[lane + WAVE * j] = ft[j]; gwft[lane + WAVE * j] = wf;
                 lft[lane + WAVE * j] = ft[j];                 // the end-of-attempt code below reads ft from LDS
             }
@@ -481,36 +562,36 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         // Gram block of sub-window s -> LDS buffer s & 1 (W*W doubles, contiguous in HBM)
         auto load_gram = [&](int s) {
             const int cnt = W * W;
-            const double *src = gwin + (size_t)s * W * W;
+            const auto src = gwin + (size_t)s * W * W;
             double *dst = Gl + (size_t)(s & 1) * W * W;
             for (int i = 2 * tid; i < cnt; i += 2 * T)
-                *reinterpret_cast<v2f64 *>(dst + i) = *reinterpret_cast<const v2f64 *>(src + i);
+                *reinterpret_cast<v2f64 *>(dst + i) = *(const MCSAS_GLOBAL v2f64 *)(src + i);
         };
         double rbA[RB][QPL], rbB[RB][QPL];
         if (nsub > 0) { load_batch(0, 0, rbA); load_gram(0); }
         // ft, w ft -> LDS; the thread's own q (apply phase): q = tid (+ 512)
         constexpr int QT = (QPL * 64 + T - 1) / T;            // q per thread in the apply phase (1 or 2)
-        double wq[QT];
+        const bool recompute = pipe_light_model(M) && pa.g.recompute_new;
+        double wq[QT], qv[QT], q3v[QT];
 #pragma unroll
         for (int x = 0; x < QT; ++x) {
             const int i = tid + T * x;
-            wq[x] = 0.;
-            if (i < qpad) { wq[x] = a.w[i]; lft[i] = gft[i]; lwft[i] = gwft[i]; }
-        }
-        {
-            const int n4 = kmax_all * 4;                       // Kb <= 256: at most two scalars per thread
-            double sv0 = 0., sv1 = 0.;
-            int ov = 0, stg = 0, sl = 0;
-            if (tid < n4) sv0 = scal[tid];
-            if (tid + PIPE_BLOCK < n4) sv1 = scal[tid + PIPE_BLOCK];
-            if (tid < kmax_all) {
-                ov = povf[tid]; stg = stage[tid];
-                int r = ri0 + tid; if (r >= N) r -= N;
-                sl = slot_of[r];
+            wq[x] = 0.; qv[x] = 1.; q3v[x] = 1.;
+            if (i < qpad) {
+                wq[x] = gw_[i]; lft[i] = gft[i]; lwft[i] = gwft[i];
+                if (recompute) { const double qq = glb(a.q)[i]; qv[x] = qq; q3v[x] = 1.0 / (qq * qq * qq); }   // as the producers' tables
             }
-            if (tid < n4) ssub[tid] = sv0;
-            if (tid + PIPE_BLOCK < n4) ssub[tid + PIPE_BLOCK] = sv1;
-            if (tid < kmax_all) { osub[tid] = ov; lstage[tid] = stg; lslot[tid] = sl; }
+        }
+        if (tid < kmax_all) {                                  // Kb <= 256 < threads
+            const int ov = povf[tid], stg = stage[tid];
+            int r = ri0 + tid; if (r >= N) r -= N;
+            const int sl = slot_of[r];
+            osub[tid] = ov; lstage[tid] = stg; lslot[tid] = sl;
+        }
+        for (int i = tid; i < kmax_all * 4; i += T) ssub[i] = scal[i];
+        if (recompute) {                                       // every proposal's Contrib record: one bulk copy per tick
+            const auto src = glb(reinterpret_cast<const double *>(pcon));
+            for (int i = tid; i < kmax_all * (PIPE_CON_BYTES / 8); i += T) lcon[i] = src[i];
         }
         if (tid == 0) { lacc[Kb] = 0; sacc[0] = 0; }
         const double invSw = 1.0 / a.Sw, SIoSw = a.SI / a.Sw, Scen = a.SII - a.SI * a.SI / a.Sw;
@@ -521,10 +602,10 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             if (stop_now) stopped = 1;                         // McSAS.stop as the host saw it when it launched this tick
             if (lane == 0) ctl[2] = (!(cur.chi2 > a.conv_crit) || stopped) ? 0 : 1;   // `live`, shared by all waves
         }
-        __syncthreads();
+        PIPE_LDS_BARRIER();
         live = ctl[2] != 0;
         double wftp[QPL];
-        load_row_pairs<QPL>(lwft, lane, wftp);
+        load_row_pairs_lds<QPL>(lwft, lane, wftp);
         // loop-invariant fit constants and the running sums, pinned in VGPRs (see MCSAS_IN_VGPR)
         double cSII = a.SII, cSI = a.SI, cScen = Scen, cSIoSw = SIoSw, cinvSw = invSw, cCrit = a.conv_crit, cnq = nqd;
         MCSAS_IN_VGPR(cSII); MCSAS_IN_VGPR(cSI); MCSAS_IN_VGPR(cScen); MCSAS_IN_VGPR(cSIoSw); MCSAS_IN_VGPR(cinvSw);
@@ -583,10 +664,10 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 // eight sums for the price of ~1.5: lane l < 8 ends up with the total of acc[4 (l&1) + 2 ((l>>1)&1) + ((l>>2)&1)]
                 const double tot = wave_sum8_transposed(acc, lane);
                 const int c = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
-                if (lane < 8 && c < RPW && wave + 8 * c < cnt) hbuf[wave + 8 * c] = tot;
+                if (lane < 8 && c < RPW && wave + 8 * c < cnt) hsub[wave + 8 * c] = tot;
             }
             MCSAS_STAMP(s1);
-            __syncthreads();                                               // B1: hbuf (and this sub-window's Gram block) complete
+            PIPE_LDS_BARRIER();                                            // B1: hsub (and this sub-window's Gram block) complete
             MCSAS_STAMP(s2);
             if (wave == 0) {
                 // ---- the W decisions of the sub-window: lane g <-> step k0 + g
@@ -594,7 +675,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 const int g = lane;
                 const bool in = g < cnt;
                 const int kg = in ? k0 + g : k0;
-                double h = hbuf[in ? g : 0];
+                double h = hsub[in ? g : 0];
                 const double sc0 = ssub[kg * 4 + 0], sc1 = ssub[kg * 4 + 1], sc2 = ssub[kg * 4 + 2];
                 const int ovg = osub[kg];
                 const double *Gs = Gl + (size_t)(s & 1) * W * W;
@@ -634,7 +715,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     if (lane == 0) {
                         lslot[acc_row] = fresh; lstage[acc_row] = freed;      // slot swap: rows are never copied
                         lacc[num_acc_win] = acc_row;
-                        sacc[1 + 2 * nacc_sub] = freed; sacc[2 + 2 * nacc_sub] = fresh;
+                        sacc[1 + 3 * nacc_sub] = freed; sacc[2 + 3 * nacc_sub] = fresh; sacc[3 + 3 * nacc_sub] = acc_row;
                     }
                     ++nacc_sub; ++num_acc_win; ++num_moves;
                     touched = true;
@@ -648,33 +729,52 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 __builtin_amdgcn_s_setprio(0);
             }
             MCSAS_STAMP(s3);
-            __syncthreads();                                               // B2: decisions published
+            PIPE_LDS_BARRIER();                                            // B2: decisions published
             MCSAS_STAMP(s4);
             live = ctl[2] != 0;
             const int nacc = sacc[0];
             if (nacc > 0) {
-                // ---- ft <- (ft - old) + new for the accepted steps, in order (mcsas.py:367,381); one q per thread
+                // ---- ft <- (ft - old) + new for the accepted steps, in order (mcsas.py:367,381); one q per thread.
+                // `new`: read back from the row slot the producer filled, or — models without an integral — evaluated
+                // here from the proposal's Contrib (same function and inputs as the producer's row: same bits) and
+                // stored into the slot the contribution now owns.
 #pragma unroll
                 for (int x = 0; x < QT; ++x) {
                     const int i = tid + T * x;
                     if (i < qpad) {
                         double f = lft[i];
-                        for (int n0 = 0; n0 < nacc; n0 += 4) {
-                            double o[4], nw[4];
+                        if (!recompute) {
+                            for (int n0 = 0; n0 < nacc; n0 += 4) {
+                                double o[4], nw[4];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int n = (n0 + u < nacc) ? n0 + u : nacc - 1;
-                                o[u] = cache[(size_t)sacc[1 + 2 * n] * qpad + i];
-                                nw[u] = cache[(size_t)sacc[2 + 2 * n] * qpad + i];
+                                for (int u = 0; u < 4; ++u) {
+                                    const int n = (n0 + u < nacc) ? n0 + u : nacc - 1;
+                                    o[u] = cache[(size_t)sacc[1 + 3 * n] * qpad + i];
+                                    nw[u] = cache[(size_t)sacc[2 + 3 * n] * qpad + i];
+                                }
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) if (n0 + u < nacc) f = (f - o[u]) + nw[u];
                             }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) if (n0 + u < nacc) f = (f - o[u]) + nw[u];
+                        } else if constexpr (pipe_light_model(M)) {
+                            // `old` rows run four accepted steps ahead of their use (a rotating queue of registers:
+                            // the loop stays rolled, one row evaluation per trip)
+                            auto old_at = [&](int n) { return n < nacc ? cache[(size_t)sacc[1 + 3 * n] * qpad + i] : 0.; };
+                            double o0 = old_at(0), o1 = old_at(1), o2 = old_at(2), o3 = old_at(3);
+                            for (int n = 0; n < nacc; ++n) {
+                                const double ocur = o0;
+                                o0 = o1; o1 = o2; o2 = o3; o3 = old_at(n + 4);
+                                const Contrib<M> c = *reinterpret_cast<const Contrib<M> *>(lcon + (size_t)sacc[3 + 3 * n] * (PIPE_CON_BYTES / 8));
+                                double nw = ocur;
+                                if (!(a.pad0 & 8192)) nw = pipe_point_intensity<M>(c, qv[x], q3v[x]);   // (diagnostic bits: timing only)
+                                if (!(a.pad0 & 4096)) cache[(size_t)sacc[2 + 3 * n] * qpad + i] = nw;
+                                f = (f - ocur) + nw;
+                            }
                         }
                         lft[i] = f; lwft[i] = wq[x] * f;
                     }
                 }
-                __syncthreads();                                           // B3: ft complete; sacc may be rewritten
-                load_row_pairs<QPL>(lwft, lane, wftp);
+                PIPE_LDS_BARRIER();                                        // B3: ft complete; sacc may be rewritten
+                load_row_pairs_lds<QPL>(lwft, lane, wftp);
             }
 #ifdef MCSAS_STAMPS
             MCSAS_STAMP(s5);
@@ -686,7 +786,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         if (wave == 0 && lane == 0) for (int i = 0; i < 8; ++i) ch.dbg[i] += ph[i];
 #endif
         if (wave == 0 && lane == 0) lacc[Kb] = num_acc_win;
-        __syncthreads();
+        PIPE_LDS_BARRIER();
         {   // write the window's slot tables back and store the accepted proposals (mcsas.py:381), all waves
             const int nacc = lacc[Kb];
             if (nacc > 0) {
@@ -711,7 +811,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
                     const double f = lft[lane + WAVE * j], wf = lwft[lane + WAVE * j];
-                    s1 += wf; s2 += wf * f; s3 += a.wI[lane + WAVE * j] * f;
+                    s1 += wf; s2 += wf * f; s3 += gwI_[lane + WAVE * j] * f;
                 }
                 wave_sum3(s1, s2, s3);
                 SC = s1; SCC = s2; SIC = s3;
@@ -734,8 +834,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
                 ft[j] = lft[lane + WAVE * j];
-                const double wf = a.w[lane + WAVE * j] * ft[j];
-                s1 += wf; s2 += wf * ft[j]; s3 += a.wI[lane + WAVE * j] * ft[j];
+                const double wf = gw_[lane + WAVE * j] * ft[j];
+                s1 += wf; s2 += wf * ft[j]; s3 += gwI_[lane + WAVE * j] * ft[j];
             }
             wave_sum3(s1, s2, s3);
             cur = solve_fit(a, s1, s2, s3);
@@ -743,8 +843,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
                 const int i = lane + WAVE * j;
-                const double r = a.I[i] - (ft[j] * cur.A + cur.b);
-                rs += a.w[i] * r * r;
+                const double r = gI_[i] - (ft[j] * cur.A + cur.b);
+                rs += gw_[i] * r * r;
             }
             cur.chi2 = wave_sum(rs) / nqd;                    // chiSqr, backgroundscalingfit.py:72-77
             converged = !(cur.chi2 > a.conv_crit);
@@ -754,7 +854,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 done = 1;
 #pragma unroll
                 for (int j = 0; j < QPL; ++j)
-                    a.fit[(size_t)rep * qpad + lane + WAVE * j] = ft[j] * cur.A + cur.b;
+                    glb(a.fit)[(size_t)rep * qpad + lane + WAVE * j] = ft[j] * cur.A + cur.b;
                 next.alive = 0;
             } else {
                 ++attempts;
@@ -776,11 +876,11 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         }
 #endif
         if (lane == 0) {
-            ch.snap[t & 1] = next;                            // read by PROD(t+2) and SCAN(t+1)
+            store_snap(&pa.chains[rep].snap[t & 1], next);    // read by PROD(t+2) and SCAN(t+1)
             ch.SC = SC; ch.SIC = SIC; ch.SCC = SCC; ch.A = cur.A; ch.b = cur.b; ch.chi2 = cur.chi2;
             ch.num_iter = num_iter; ch.num_moves = num_moves; ch.total_steps = total_steps;
             ch.draw_pos = draw_pos; ch.attempts = attempts; ch.converged = converged; ch.stopped = stopped;
-            if (overflow) atomicOr(&ch.overflow, 1);
+            if (overflow) atomicOr(&pa.chains[rep].overflow, 1);
             if (done) {
                 ch.done = 1;
                 ChainOut o;
@@ -810,10 +910,17 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
     const PipeArgs &pa = *pap;
     const int R = pa.c.n_reps, b = blockIdx.x, t = tick;
     if (b < R) {
-        if (t >= 0) pipe_scan_block<QPL>(pa, lds, b, t, stop_now);
+        if (t >= 0) pipe_scan_block<M, QPL>(pa, lds, b, t, stop_now);
     } else {
+        // chain-major block -> (chain, sub-window) map: round-robin dispatch then spreads every chain's blocks
+        // over the 8 XCDs.  The XCD-aware alternative (diagnostic bit 128: chain r's producer blocks on block ids
+        // congruent to r modulo 8, i.e. on the XCD of its scan block, so that next tick's d rows sit in that
+        // XCD's L2) measured 10-40 % SLOWER on config 2: 50 chains x (1 + gy) blocks do not divide over 8 XCDs of
+        // 32 CUs with one block per CU — two XCDs get 35 blocks and their chains take two rounds.
         const int gy = pa.g.prod_blocks_y;
-        pipe_prod_block<M, QPL>(pa, lds, (b - R) / gy, (b - R) % gy, gy, t + 1);
+        int rep = (b - R) / gy, y = (b - R) % gy;
+        if (pa.c.pad0 & 128) { const int x = b & 7, j = (b - R) >> 3; rep = x + 8 * (j / gy); y = j % gy; }
+        if (rep < R) pipe_prod_block<M, QPL>(pa, lds, rep, y, gy, t + 1);
     }
 }
 

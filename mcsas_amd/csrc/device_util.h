@@ -7,6 +7,14 @@ namespace mcsas {
 
 constexpr int WAVE = 64;
 
+// Global-address-space view of a pointer that was read out of an argument block in memory.  The compiler can
+// only prove "global" for pointers that are kernel arguments themselves; everything else becomes flat_load /
+// flat_store, which count in vmcnt AND lgkmcnt, return out of order and therefore force `s_waitcnt vmcnt(0)
+// lgkmcnt(0)` before the first use — no counted waits, no load running ahead of its consumer.
+#define MCSAS_GLOBAL __attribute__((address_space(1)))
+template <class T> __device__ __forceinline__ MCSAS_GLOBAL T *glb(T *p) { return (MCSAS_GLOBAL T *)p; }
+template <class T> __device__ __forceinline__ const MCSAS_GLOBAL T *glb(const T *p) { return (const MCSAS_GLOBAL T *)p; }
+
 // ---- cross-lane (DPP) -----------------------------------------------------------------------
 // DPP controls (CDNA ISA): quad_perm 0x00-0xFF, row_mirror 0x140, row_half_mirror 0x141,
 // row_bcast15 0x142, row_bcast31 0x143.

@@ -249,7 +249,7 @@ static int rowtab_doubles_host(int model_id, int K) {
 
 static int fill_model_args(const mcsas_problem *p, ModelArgs *m) {
     if (p->model_id < 0 || p->model_id >= MCSAS_MODEL_COUNT) return fail(MCSAS_EINVAL, "unknown model_id %d", p->model_id);
-    if (p->n_active < 1 || p->n_active > MCSAS_MAX_ACTIVE) return fail(MCSAS_EINVAL, "n_active %d out of range", p->n_active);
+    if (p->n_active < 0 || p->n_active > MCSAS_MAX_ACTIVE) return fail(MCSAS_EINVAL, "n_active %d out of range", p->n_active);
     memset(m, 0, sizeof *m);
     m->model_id = p->model_id; m->n_active = p->n_active; m->comp_exp = p->comp_exp;
     for (int i = 0; i < MCSAS_MAX_PARAMS; ++i) m->params[i] = p->params[i];
@@ -349,6 +349,7 @@ struct mcsas_plan {
     PipeArgs pipe{};
     PipeChain *d_chains = nullptr;
     double *d_ft = nullptr, *d_wft = nullptr, *d_dwin = nullptr, *d_gwin = nullptr, *d_scal = nullptr, *d_pval = nullptr;
+    unsigned char *d_pcon = nullptr;
     int32_t *d_slot_of = nullptr, *d_stage = nullptr, *d_povf = nullptr;
     int32_t *h_done = nullptr;          // pinned + mapped: scan kernels count finished chains into it
     PipeArgs *d_pipeargs = nullptr;     // the argument block the tick kernels read (device copy)
@@ -397,7 +398,7 @@ extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     hipFree(pl->d_rset); hipFree(pl->d_cache); hipFree(pl->d_fit); hipFree(pl->d_replay); hipFree(pl->d_out);
     if (pl->h_stop) hipHostFree(pl->h_stop);
     if (pl->h_done) hipHostFree(pl->h_done);
-    hipFree(pl->d_pipeargs); hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_gwin); hipFree(pl->d_scal);
+    hipFree(pl->d_pipeargs); hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_gwin); hipFree(pl->d_scal); hipFree(pl->d_pcon);
     hipFree(pl->d_pval); hipFree(pl->d_slot_of); hipFree(pl->d_stage); hipFree(pl->d_povf);
     for (int i = 0; i < mcsas_plan::RING; ++i) {
         if (pl->evP[i]) hipEventDestroy(pl->evP[i]);
@@ -417,6 +418,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         return fail(MCSAS_EINVAL, "mcsas_problem size %u, library expects %zu (ABI mismatch)", p->struct_size, sizeof(mcsas_problem));
     if (p->nq < 1 || !p->q || !p->intensity || !p->sigma) return fail(MCSAS_EINVAL, "nq/q/intensity/sigma missing");
     if (p->n_contrib < 1 || p->n_reps < 1) return fail(MCSAS_EINVAL, "n_contrib and n_reps must be >= 1");
+    if (p->n_active < 1) return fail(MCSAS_EINVAL, "a plan needs an active parameter (mcsas_hip_analyse answers the no-active-parameter case itself)");
     if (p->max_iter < 0 || p->max_retries < 0) return fail(MCSAS_EINVAL, "max_iter/max_retries negative");
     if (p->replay_stream && p->replay_len < 1) return fail(MCSAS_EINVAL, "replay_len must be >= 1");
     ModelArgs margs;
@@ -455,6 +457,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     const int tab_shared = table_doubles_host(p->model_id, margs.int_div), tab_row = rowtab_doubles_host(p->model_id, margs.int_div);
     const bool heavy_rows = tab_shared > 0 || margs.smear_nk > 0;
     const int rpw_req = (p->reserved0 >> 8) & 15;          // tuning / diagnostics: rows per producer wave of the pipeline, 0 = automatic
+    const int recompute_req = (p->reserved0 >> 16) & 1;    // tuning: 1 = producers keep no `new` rows, the scan block re-evaluates accepted ones
 #define TABD(waves_per_block) (tab_shared + (waves_per_block) * tab_row)
     // execution mode (results do not depend on it)
     int mode = p->exec_mode;
@@ -468,7 +471,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             // one workgroup per chain up to ~400, one wavefront per chain beyond; rows that cost an integral
             // each keep the workgroup's seven producer waves per chain until the chains alone fill the SIMDs
             if (p->n_reps >= (heavy_rows ? 1024 : 448)) mode = MCSAS_EXEC_WAVE;
-            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
+            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, recompute_req, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
             else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
             else mode = MCSAS_EXEC_WAVE;
         }
@@ -508,7 +511,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: needs 2*window <= n_contrib and the window in LDS (nq=%d, n_contrib=%d, waves=%d)", p->nq, (int)N, waves); }
         cache_rows = (int)N + 2 * pl->wg.window;
     } else if (mode == MCSAS_EXEC_PIPELINE) {
-        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
+        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, recompute_req, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
         cache_rows = (int)N + 2 * pl->pipe.g.kb;
     }
     size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
@@ -567,6 +570,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         PCHK(hipMalloc(&pl->d_dwin, sizeof(double) * R * 2 * Kb * qpad));
         PCHK(hipMalloc(&pl->d_gwin, sizeof(double) * R * 2 * Kb * pa.g.w));
         PCHK(hipMalloc(&pl->d_scal, sizeof(double) * R * 2 * Kb * 4));
+        PCHK(hipMalloc(&pl->d_pcon, (size_t)R * 2 * Kb * PIPE_CON_BYTES));
         PCHK(hipMalloc(&pl->d_pval, sizeof(double) * R * 2 * Kb * MCSAS_MAX_ACTIVE));
         PCHK(hipMalloc(&pl->d_povf, sizeof(int32_t) * R * 2 * Kb));
         PCHK(hipMemset(pl->d_povf, 0, sizeof(int32_t) * R * 2 * Kb));
@@ -578,7 +582,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             PCHK(hipEventCreateWithFlags(&pl->evS[i], hipEventDisableTiming));
         pa.c = a;
         pa.chains = pl->d_chains; pa.ft = pl->d_ft; pa.wft = pl->d_wft; pa.slot_of = pl->d_slot_of;
-        pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.gwin = pl->d_gwin; pa.scal = pl->d_scal; pa.pval = pl->d_pval;
+        pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.gwin = pl->d_gwin; pa.scal = pl->d_scal; pa.pcon = pl->d_pcon; pa.pval = pl->d_pval;
         pa.povf = pl->d_povf; pa.n_done = d_done; pa.tick = 0;
         pl->lds_bytes = std::max(pa.g.prod_lds, pa.g.scan_lds);
     }
@@ -618,7 +622,8 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     const long long win_per_attempt = (long long)(pl->prob.max_iter / Kb) + 4;
     const long long attempts = (long long)pl->prob.max_retries + 1;
     const long long max_ticks = (win_per_attempt >= TICK_CAP / attempts) ? TICK_CAP : std::min(attempts * win_per_attempt + 4, TICK_CAP);
-    const dim3 grid(R + R * pa.g.prod_blocks_y);
+    // scan blocks + producer blocks (chain-major; 8 XCD classes of ceil(R/8) chains each with diagnostic bit 128)
+    const dim3 grid((pl->args.pad0 & 128) ? R + 8 * ((R + 7) / 8) * pa.g.prod_blocks_y : R + R * pa.g.prod_blocks_y);
     long long t = -1;                                    // launch t = {SCAN(t), PROD(t+1)}
     for (; t < max_ticks; ++t) {
         if (t >= mcsas_plan::RING && (t % 16) == 0) {
@@ -770,6 +775,29 @@ extern "C" int mcsas_hip_plan_total_steps(mcsas_plan *pl, int64_t *steps) {
 
 extern "C" int mcsas_hip_analyse(const mcsas_problem *p, mcsas_result *res) {
     if (!res) return fail(MCSAS_EINVAL, "null result");
+    if (p && p->n_active == 0) {
+        // No active fit parameter (mcsas.py:198-201, 238-239, 322-323): analyse() runs ONE repetition of ONE
+        // contribution, mcFit returns the model's intensity at its fixed parameter values with conval = -1,
+        // scaling 1, background 0, and the repetition loop leaves without retrying.  Result arrays are sized
+        // for n_contrib = n_reps = 1 whatever the problem says.
+        if (res->struct_size != sizeof(mcsas_result)) return fail(MCSAS_EINVAL, "mcsas_result size mismatch");
+        if (p->struct_size != sizeof(mcsas_problem)) return fail(MCSAS_EINVAL, "mcsas_problem size mismatch (ABI)");
+        if (p->nq < 1 || !p->q) return fail(MCSAS_EINVAL, "nq/q missing");
+        std::vector<double> cum(p->nq);
+        int rc0 = mcsas_hip_model_calc(p, nullptr, 1, cum.data(), nullptr, nullptr, nullptr, nullptr);
+        if (rc0) return rc0;
+        if (res->fit) for (int k = 0; k < p->nq; ++k) res->fit[k] = cum[k];
+        if (res->chisq) res->chisq[0] = -1.0;
+        if (res->scaling) res->scaling[0] = 1.0;
+        if (res->background) res->background[0] = 0.0;
+        if (res->num_iter) res->num_iter[0] = 0;
+        if (res->num_moves) res->num_moves[0] = 0;
+        if (res->attempts) res->attempts[0] = 1;
+        if (res->converged) res->converged[0] = 1;
+        if (res->seconds) res->seconds[0] = 0.0;
+        if (res->draws) res->draws[0] = 0;
+        return MCSAS_OK;
+    }
     mcsas_plan *pl = nullptr;
     int rc = mcsas_hip_plan_create(p, &pl);
     if (rc) return rc;
@@ -788,19 +816,19 @@ template <typename T> struct DevBuf {
 
 extern "C" int mcsas_hip_model_calc(const mcsas_problem *p, const double *pset, int32_t n, double *cum_int,
                                     double *vset, double *wset, double *sset, double *rows) {
-    if (!p || !pset || n < 1 || !p->q || p->nq < 1) return fail(MCSAS_EINVAL, "bad argument");
+    if (!p || n < 1 || !p->q || p->nq < 1 || (!pset && p->n_active > 0)) return fail(MCSAS_EINVAL, "bad argument");
     ModelArgs m;
     int rc = fill_model_args(p, &m);
     if (rc) return rc;
     DeviceGuard dev_guard;
     rc = select_device(p->device);
     if (rc) return rc;
-    const size_t Q = p->nq, P = p->n_active;
+    const size_t Q = p->nq, P = p->n_active;                 // P == 0: every row is the model at its fixed values
     DevBuf<double> dq, dp, dr, dv, dw, ds, dc;
     HIPCHK(dq.alloc(Q)); HIPCHK(dp.alloc(n * P)); HIPCHK(dr.alloc((size_t)n * Q));
     HIPCHK(dv.alloc(n)); HIPCHK(dw.alloc(n)); HIPCHK(ds.alloc(n)); HIPCHK(dc.alloc(Q));
     HIPCHK(hipMemcpy(dq.p, p->q, sizeof(double) * Q, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dp.p, pset, sizeof(double) * n * P, hipMemcpyHostToDevice));
+    if (P > 0) HIPCHK(hipMemcpy(dp.p, pset, sizeof(double) * n * P, hipMemcpyHostToDevice));
     SmearDev smear;
     rc = smear.upload(p, p->nq, &m);
     if (rc) return rc;

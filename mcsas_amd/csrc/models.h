@@ -46,7 +46,7 @@ template <int M>
 __device__ __forceinline__ double smeared_intensity(const Contrib<M> &c, const double *locs_t, const double *cw,
                                                     int nk, int stride, int i, const double *tab) {
     double acc = 0.;
-    for (int m = 0; m < nk; ++m) acc = fma(cw[m], c.intensity(locs_t[(size_t)m * stride + i], tab), acc);
+    for (int m = 0; m < nk; ++m) acc = fma(glb(cw)[m], c.intensity(glb(locs_t)[(size_t)m * stride + i], tab), acc);
     return acc;
 }
 

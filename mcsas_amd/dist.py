@@ -42,15 +42,16 @@ def gather_results(local: dict, n_reps: int, device=None):
     counts = [shard_reps(n_reps, ws, r)[1] for r in range(ws)]
     keys = sorted(local)
     shapes = {k: np.asarray(local[k]).shape[1:] for k in keys}
+    widths = {k: int(np.prod(shapes[k])) if len(shapes[k]) else 1 for k in keys}
     rl = counts[rank]
-    packed = np.concatenate([np.asarray(local[k], dtype=np.float64).reshape(rl, -1) for k in keys], axis=1)
+    # explicit widths: a rank that owns no repetition (world_size > n_reps) still joins the collective
+    packed = np.concatenate([np.asarray(local[k], dtype=np.float64).reshape(rl, widths[k]) for k in keys], axis=1)
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.from_numpy(np.ascontiguousarray(packed)).to(device)
     full = _gather_var(t, counts, dist, device).cpu().numpy()
     out, col = {}, 0
     for k in keys:
-        width = int(np.prod(shapes[k])) if len(shapes[k]) else 1
-        out[k] = full[:, col:col + width].reshape((n_reps,) + tuple(shapes[k]))
-        col += width
+        out[k] = full[:, col:col + widths[k]].reshape((n_reps,) + tuple(shapes[k]))
+        col += widths[k]
     return out

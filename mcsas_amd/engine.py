@@ -72,8 +72,8 @@ class HipProblem:
     """Owns the numpy buffers a `mcsas_problem` points at (ctypes does not keep them alive)."""
 
     def __init__(self, model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None, smear=None):
-        if model.n_active < 1 or model.n_active > MAX_ACTIVE:
-            raise ValueError("1..%d active parameters supported, got %d" % (MAX_ACTIVE, model.n_active))
+        if model.n_active < 0 or model.n_active > MAX_ACTIVE:
+            raise ValueError("0..%d active parameters supported, got %d" % (MAX_ACTIVE, model.n_active))
         self.q, self.I, self.sigma = f64(q).ravel(), f64(intensity).ravel(), f64(sigma).ravel()
         if not (len(self.q) == len(self.I) == len(self.sigma)):
             raise ValueError("q, intensity and sigma must have the same length")

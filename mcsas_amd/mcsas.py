@@ -108,8 +108,9 @@ class McSAS(object):
             self.result = []
         data, model = self.data, self.model
         if not any(isActiveFitParam(p) for p in model.params()):
-            raise NotImplementedError("no active fit parameter: nothing for the Monte-Carlo kernels to do")
-        numContribs, numReps = self.numContribs(), self.numReps()
+            numContribs, numReps = 1, 1                      # mcsas.py:198-199: nothing active, nothing to fit
+        else:
+            numContribs, numReps = self.numContribs(), self.numReps()
         st = self._settings(numContribs, numReps)
         setup = setup_from_model(model, data)
         smear = data.smearArgs(model) if hasattr(data, "smearArgs") else None   # sasmodel.py:56-60

@@ -41,7 +41,7 @@ def _worker(rank, world, port, R, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("R", [5, 4])
+@pytest.mark.parametrize("R", [5, 4, 1])
 def test_two_rank_gather_restores_rep_order(tmp_path, R):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_worker, args=(2, port, R, str(tmp_path)), nprocs=2, join=True)
@@ -55,3 +55,46 @@ def test_two_rank_gather_restores_rep_order(tmp_path, R):
 def test_single_process_is_a_passthrough():
     out = gather_results(dict(a=np.arange(6.0).reshape(3, 2)), 3)
     np.testing.assert_array_equal(out["a"], np.arange(6.0).reshape(3, 2))
+
+
+def _run_bench(tmp_path, gpus, extra, tag):
+    """bench.py's own multi-rank code path on CPU: MCSAS_BENCH_DRY=1 swaps the GPU plan for a payload that
+    depends only on (seed, global repetition index); gloo carries the all-gather.  --gpus N with no launcher
+    around makes bench.py start its N ranks itself."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = os.path.join(str(tmp_path), tag + ".npz")
+    env = dict(os.environ, MCSAS_BENCH_DRY="1", MCSAS_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+           "--dump", dump] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line), np.load(dump)
+
+
+@pytest.mark.parametrize("extra", [["--scaling", "strong"], ["--scaling", "strong", "--config", "5"]])
+def test_bench_multi_rank_path_equals_single_rank(tmp_path, extra):
+    """Strong scaling shards the config's repetitions (50, or config 5's 100) over the ranks with chain id =
+    global repetition index: the gathered result of 2 ranks equals the 1-rank run repetition for repetition,
+    and the JSON line reports the ranks it actually saw."""
+    one, a1 = _run_bench(tmp_path, 1, extra, "one")
+    two, a2 = _run_bench(tmp_path, 2, extra, "two")
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["ranks_seen"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["reps_total"] == one["config"]["reps_total"]
+    assert two["value"] is None and two["data"] == "dry-run"          # never a measurement
+    for k in ("contribs", "fit", "chisq", "scaling", "background"):
+        np.testing.assert_array_equal(a1[k], a2[k])
+
+
+def test_bench_refuses_a_world_size_it_was_not_asked_for(tmp_path):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCSAS_BENCH_DRY="1", MCSAS_BENCH_BACKEND="gloo", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout

@@ -97,7 +97,8 @@ def test_replay_trajectories_vs_reference(name, cache, waves):
     np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
     rtol = 1e-5 if "posbg" in name else 1e-7
     np.testing.assert_allclose(res.chisq[0], float(g["res_conval"]), rtol=rtol)
-    np.testing.assert_allclose(res.fit[:, 0], g["res_fit"], rtol=1e-6)
+    # (atol: scale * model + background crosses zero on the worm data file, whose intensity spans 9 decades)
+    np.testing.assert_allclose(res.fit[:, 0], g["res_fit"], rtol=1e-6, atol=1e-12 * np.abs(g["res_fit"]).max())
     np.testing.assert_allclose(res.scaling[0], float(g["res_scaling"]), rtol=1e-6)
     assert res.draws[0] == (0 if st.start_from_minimum else ost.n_contrib * spec.n_active) + res.num_iter[0] * spec.n_active
 
@@ -617,3 +618,94 @@ def test_uncertainty_floor_special_values():
     ref = O.prepare_uncertainty(I, su, 0.1)
     np.testing.assert_array_equal(got, ref)
     assert got[0] == 1.0 and got[1] == 5.0 and got[2] == 1.0 and got[3] == 0.3 and np.isinf(got[4:]).all()
+
+
+# ----------------------------------------------------------------------------- round 2: row edges
+@pytest.mark.parametrize("mode", [engine.EXEC_WAVE, engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE])
+def test_exponential2_and_3_generators_on_device(mode):
+    """RandomExponential2 / RandomExponential3 (numbergenerator.py:181-189) through the device-side gen_transform:
+    (1) the initial parameter set drawn from a replayed uniform stream equals the reference's own transform of the
+    same uniforms (g6_generators.npz) scaled into the active range; (2) free-running chains with those generators
+    follow the oracle."""
+    g = load("g6_generators.npz")
+    u = g["u"]
+    lo, hi = [2e-9, 3e-9], [9e-8, 4e-7]
+    m, spec = make_models("gausschain", lo, hi, [2, 3])
+    N = 32
+    q, I, sig = _synthetic(100)
+    st = engine.Settings(n_contrib=N, n_reps=1, max_iter=0, conv_crit=0.0, max_retries=0, exec_mode=mode)
+    res = engine.analyse(m.setup(), q, I, sig, st, replay=np.concatenate([u, u])[None, :])
+    want = np.stack([g["exp2"][:N] * (hi[0] - lo[0]) + lo[0], g["exp3"][N:2 * N] * (hi[1] - lo[1]) + lo[1]], axis=1)
+    np.testing.assert_allclose(res.contribs[:, :, 0], want, rtol=4e-16)       # device pow against numpy's: one ulp
+    assert res.num_iter[0] == 0 and res.draws[0] == 2 * N
+    st = engine.Settings(n_contrib=N, n_reps=3, max_iter=150, conv_crit=1e-9, max_retries=0, seed=99, exec_mode=mode)
+    res = engine.analyse(m.setup(), q, I, sig, st)
+    ost = O.Settings(n_contrib=N, n_reps=1, max_iter=150, conv_crit=1e-9)
+    for r in range(3):
+        ref = O.mc_fit(spec, q, I, sig, [I.min(), I.max()], [q.min(), q.max()], ost, O.PhiloxStream(99, r), method="closed")
+        assert res.num_moves[r] == ref.num_moves and res.num_iter[r] == ref.num_iter
+        np.testing.assert_allclose(res.contribs[:, :, r], ref.rset, rtol=1e-12)
+        np.testing.assert_allclose(res.chisq[r], ref.conval, rtol=1e-7)
+
+
+def test_config5_as_named_full_size_properties():
+    """BASELINE config 5 as named — the Kholodenko fit on testdata/sasfit_kho-1-10-1000.dat at 512 q x 600
+    contributions — with the per-GPU share of its 100 repetitions (13): the three execution modes walk identical
+    chains, chi² never increases with the budget, the reported chi² is the chi² of the reported fit, parameters stay
+    inside the model's default active ranges.  (The reference's own 300-step chain on this data is replayed in
+    test_replay_trajectories_vs_reference[g9_kho_q512].)"""
+    from bench import kholodenko_file_data
+    q, I, sig = kholodenko_file_data()
+    assert len(q) == 512
+    m, _ = make_models("kholodenko")
+    setup = m.setup()
+    prev = None
+    for steps in (24, 96, 700):
+        res = {}
+        for mode in (engine.EXEC_PIPELINE, engine.EXEC_WAVE, engine.EXEC_WORKGROUP):
+            if mode != engine.EXEC_PIPELINE and steps != 24:
+                continue
+            st = engine.Settings(n_contrib=600, n_reps=13, max_iter=steps, conv_crit=0.0, max_retries=0, seed=5, exec_mode=mode)
+            res[mode] = engine.analyse(setup, q, I, sig, st)
+        r = res[engine.EXEC_PIPELINE]
+        for mode, o in res.items():
+            np.testing.assert_array_equal(o.num_moves, r.num_moves)
+            np.testing.assert_array_equal(o.contribs, r.contribs)
+            np.testing.assert_allclose(o.chisq, r.chisq, rtol=1e-9)
+        assert (r.num_iter == steps).all()
+        direct = (((I[:, None] - r.fit) / sig[:, None])**2).sum(axis=0) / len(q)
+        np.testing.assert_allclose(r.chisq, direct, rtol=1e-9)
+        for col in range(3):
+            assert (r.contribs[:, col, :] >= setup.gen_lo[col]).all() and (r.contribs[:, col, :] <= setup.gen_hi[col]).all()
+        if prev is not None:
+            assert (r.chisq <= prev * (1 + 1e-12)).all()
+        prev = r.chisq.copy()
+
+
+def test_no_active_parameter_returns_the_model_intensity():
+    """mcsas.py:198-201, 238-239, 322-323: with no active fit parameter analyse() runs one repetition of one
+    contribution and mcFit hands back the model intensity at the fixed parameter values (conval -1, scaling 1,
+    background 0); the result dict has contribs of shape (1, 0, 1) and histogram() has nothing to do."""
+    q, I, sig = _synthetic(100)
+    m = mcsas_amd.Sphere()
+    m.radius.setValue(2.5e-8)
+    m.radius.setActive(False)
+    assert m.activeParamCount() == 0
+    algo = mcsas_amd.McSAS(seed=1)
+    algo.model = m
+    algo.data = mcsas_amd.SASData(q, I, sig)
+    algo.calc()
+    res = algo.result[0]
+    assert res["contribs"].shape == (1, 0, 1)
+    _, spec = make_models("sphere")
+    want = O.calc_intensity(spec, q, [2.5e-8], algo.compensationExponent())[0]
+    np.testing.assert_allclose(res["fitMeasValMean"][0], want, rtol=1e-9)
+    np.testing.assert_array_equal(res["fitMeasValStd"], 0.0)
+    assert res["scaling"] == (1.0, 0.0) and res["background"] == (0.0, 0.0) and res["numIter"] == 0.0
+    assert algo.details.chisq[0] == -1.0
+    # the library entry point with n_active = 0 directly, and a plan (which needs something to fit) refusing it
+    st = engine.Settings(n_contrib=300, n_reps=10)
+    r = engine.analyse(m.setup(), q, I, sig, engine.Settings(n_contrib=1, n_reps=1))
+    np.testing.assert_allclose(r.fit[:, 0], want, rtol=1e-9)
+    with pytest.raises(mcsas_amd._lib.McSASHipError):
+        engine.Plan(m.setup(), q, I, sig, st)
