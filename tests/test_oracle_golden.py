@@ -112,7 +112,8 @@ def test_g4_replay_trajectories(name, method):
     if "posbg" in name and method == "closed":
         rtol = 1e-5
     np.testing.assert_allclose(res.conval, float(g["res_conval"]), rtol=rtol)
-    np.testing.assert_allclose(res.fit, g["res_fit"], rtol=1e-6)
+    # (atol: scale * model + background crosses zero on the worm data file, whose intensity spans 9 decades)
+    np.testing.assert_allclose(res.fit, g["res_fit"], rtol=1e-6, atol=1e-12 * np.abs(g["res_fit"]).max())
     np.testing.assert_allclose(res.scaling, float(g["res_scaling"]), rtol=1e-6)
 
 
