@@ -67,7 +67,7 @@ struct PipeGeom {
     int32_t scan_waves;           // waves of a scan block
     int32_t qpl;
     int32_t gram_off;             // producer LDS: offset (doubles) of the Gram reduction buffer
-    int32_t recompute_new;        // 1: producers do not store the proposals' rows; the scan block re-evaluates the accepted ones
+    int32_t sub_per_block;        // scan sub-windows per producer block (8 * rows_per_wave / w)
     uint64_t prod_lds, scan_lds;
 };
 
@@ -81,7 +81,6 @@ struct PipeArgs {
     double *dwin;                 // [R][2][kb][qpad]   d rows of the window
     double *gwin;                 // [R][2][kb][w]      Gram blocks: row = step in the window, column = step in ITS sub-window
     double *scal;                 // [R][2][kb][4]   a = Σ w d, e = Σ wI d, g = Σ w d² of every step's row
-    unsigned char *pcon;          // [R][2][kb][PIPE_CON_BYTES]  the proposal's Contrib<M> (what its row evaluation needs)
     double *pval;                 // [R][2][kb][MAX_ACTIVE]
     int32_t *povf;                // [R][2][kb]
     int32_t *n_done;              // host-mapped: number of finished chains
@@ -103,11 +102,10 @@ __device__ __forceinline__ void store_snap(PipeSnap *p, const PipeSnap &s) {
 
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
 constexpr int PIPE_WAVES = PIPE_BLOCK / 64;
-constexpr int PIPE_CON_BYTES = 96;   // >= sizeof(Contrib<M>) of the models whose accepted rows the scan block re-evaluates
 constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
-static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int recompute_req, PipeGeom *g) {
+static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, PipeGeom *g) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
@@ -141,31 +139,24 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         for (int c = 0; c < 6 && !rpw; ++c)                   // a window within 15 % of the largest is as good
             if (kbs[c] > 0 && 20 * kbs[c] >= 17 * best_kb) { rpw = order[c]; by = kbs[c] / (8 * rpw); }
     }
-    g->kb = by * 8 * rpw; g->qpl = qpl; g->w = 8 * rpw;
-    g->recompute_new = (heavy_rows || !recompute_req) ? 0 : 1;
+    g->kb = by * 8 * rpw; g->qpl = qpl;
+    // scan sub-window: the largest multiple of 8 that divides the producer block's rows and whose d rows fit the
+    // scan block's LDS row buffer (the accepted rows are applied to ft from there, not from HBM)
+    g->w = 8;
+    for (int ws = 8; ws <= 8 * rpw && ws <= 64; ws += 8)
+        if ((8 * rpw) % ws == 0 && sizeof(double) * (size_t)ws * qpad <= 96 * 1024) g->w = ws;
+    g->sub_per_block = 8 * rpw / g->w;
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
     g->gram_off = 4 * qpad + tab_doubles;
     g->prod_lds = sizeof(double) * ((size_t)g->gram_off + (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256);
     g->scan_waves = PIPE_WAVES;
-    // scan block LDS: two Gram blocks (double buffer), ft and w*ft, the window's scalars, h of the sub-window,
-    // h, a, e, g of the sub-window, flags / slot tables / accepted lists
-    g->scan_lds = sizeof(double) * (2 * (size_t)g->w * g->w + 2 * (size_t)qpad + (size_t)g->kb * (PIPE_CON_BYTES / 8 + 4) + 64)
-                + sizeof(int32_t) * (4 * (size_t)g->kb + 1 + 3 * 64 + 4 + 8) + 64;
+    // scan block LDS: the sub-window's d rows, two Gram blocks (double buffer), ft and w*ft, the window's scalars, h of
+    // the sub-window, flags / slot tables / accepted lists
+    g->scan_lds = sizeof(double) * ((size_t)g->w * qpad + 2 * (size_t)g->w * g->w + 2 * (size_t)qpad + (size_t)g->kb * 4 + 64)
+                + sizeof(int32_t) * (4 * (size_t)g->kb + 1 + 1 + 64 + 4 + 8) + 64;
     if (g->scan_lds > 160 * 1024 || g->prod_lds > 160 * 1024) return 1;
     return 0;
-}
-
-// Models whose accepted rows the scan block re-evaluates itself (a few hundred instructions per row) instead of
-// having every proposal's row written to HBM by the producers (4 KB per step, 94 % of them rejected): the ones
-// without an orientation / contour integral.  Same function, same inputs as RowEval -> the same bits.
-constexpr bool pipe_light_model(int m) {
-    return m == MCSAS_MODEL_SPHERE || m == MCSAS_MODEL_SPH_CS || m == MCSAS_MODEL_GAUSS_CHAIN || m == MCSAS_MODEL_LMA_SPHERE;
-}
-template <int M>
-__device__ __forceinline__ double pipe_point_intensity(const Contrib<M> &c, double q, double q3inv) {
-    if constexpr (M == MCSAS_MODEL_SPHERE) return c.fast ? c.intensity_fast(q, q3inv) : c.intensity(q, nullptr);
-    else return c.intensity(q, nullptr);
 }
 
 // one row of the window buffers as every kernel here holds it in registers: 16-byte loads, lane l and
@@ -385,8 +376,6 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
     auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
     auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
-    unsigned char *pcon = pa.pcon + ((size_t)rep * 2 + buf) * Kb * PIPE_CON_BYTES;
-    const bool keep_new = !(pipe_light_model(M) && pa.g.recompute_new);
     int ri = (int)(s0 % N);
     // row slots of all my rows in one round trip (lane i <-> my row i): the row loop below then starts its loads
     // of `old` without waiting for a dependent index load per row
@@ -395,18 +384,31 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
         int r = ri + lane; if (r >= N) r -= N;
         my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + k0 + lane];
     }
+    // the `old` row of step i + 1 is requested before the row of step i is evaluated: under a full chip an Infinity
+    // Cache / HBM round trip is longer than one sphere row evaluation, one row of lookahead hides it
+    double onext[QPL];
+    {
+        const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) onext[j] = orow0[WAVE * j];
+    }
     for (int i = 0; i < rpw; ++i) {
         const int k = k0 + i;
         if (s0 + i >= a.max_iter) break;
         const int bl = __builtin_amdgcn_readfirstlane(i);
         const Contrib<M> cnew = prop.bcast(bl);
-        const int oslot = __builtin_amdgcn_readlane(my_oslot, bl), sslot = __builtin_amdgcn_readlane(my_sslot, bl);
-        const auto orow = cache + (size_t)oslot * qpad + lane;
+        const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
         const auto nrow = cache + (size_t)sslot * qpad + lane;
         const auto dr = dwin + (size_t)k * qpad + lane;
         double d[QPL], nwv[QPL];
 #pragma unroll
-        for (int j = 0; j < QPL; ++j) d[j] = orow[WAVE * j];
+        for (int j = 0; j < QPL; ++j) d[j] = onext[j];
+        {
+            const int bn = __builtin_amdgcn_readfirstlane(i + 1 < rpw ? i + 1 : i);
+            const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bn) * qpad + lane;
+#pragma unroll
+            for (int j = 0; j < QPL; ++j) onext[j] = orow[WAVE * j];
+        }
         RowEval<M, QPL>::run(cnew, qt, lane, nwv);
         // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  (Taking the
         // sums in the scan block's pass over the row instead was measured: its single h pass is the serial part of a
@@ -415,7 +417,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
 #pragma unroll
         for (int j = 0; j < QPL; ++j) {
             const int iq = lane + WAVE * j;
-            if (keep_new) nrow[WAVE * j] = nwv[j];
+            nrow[WAVE * j] = nwv[j];
             d[j] = nwv[j] - d[j];
             dr[WAVE * j] = d[j];
             const double wd = lw[iq] * d[j];
@@ -429,10 +431,6 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
                 const double v = readlane_f64(prow[p], bl);
                 if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
             }
-        if constexpr (pipe_light_model(M)) {
-            static_assert(sizeof(Contrib<M>) <= PIPE_CON_BYTES, "PIPE_CON_BYTES too small for this model");
-            if (!keep_new && lane == 0) *reinterpret_cast<Contrib<M> *>(pcon + (size_t)k * PIPE_CON_BYTES) = cnew;
-        }
         const int ov = __builtin_amdgcn_readlane(pov, bl);
         if (lane == 0) povf[k] = ov;
         ri = (ri + 1 == N) ? 0 : ri + 1;
@@ -444,12 +442,16 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     __syncthreads();
     MCSAS_STAMP(pp2);
     {
-        const int W = pa.g.w;
-        const int64_t left = a.max_iter - (w * Kb + (int64_t)by * W);
-        const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
-        if (nvalid > 1)
-            pipe_prod_gram<QPL>(dwin + (size_t)by * W * qpad, qpad, W, nvalid, lw, lds + pa.g.gram_off,
-                                glb(pa.gwin) + (((size_t)rep * 2 + buf) * Kb + (size_t)by * W) * W);
+        const int W = pa.g.w, nsb = pa.g.sub_per_block;       // the block's rows are nsb scan sub-windows of W steps
+        for (int ss = 0; ss < nsb; ++ss) {
+            const int sub = by * nsb + ss;                    // sub-window index within the window
+            const int64_t left = a.max_iter - (w * Kb + (int64_t)sub * W);
+            const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
+            if (nvalid > 1)
+                pipe_prod_gram<QPL>(dwin + (size_t)sub * W * qpad, qpad, W, nvalid, lw, lds + pa.g.gram_off,
+                                    glb(pa.gwin) + (((size_t)rep * 2 + buf) * Kb + (size_t)sub * W) * W);
+            if (ss + 1 < nsb) PIPE_LDS_BARRIER();             // the reduction buffer is reused
+        }
     }
 #ifdef MCSAS_STAMPS
     MCSAS_STAMP(pp3);
@@ -471,7 +473,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
     const ChainArgs &a = pa.c;
     // the wave index is wave-uniform: keep it (and the row bookkeeping that hangs on it) on the scalar unit
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb, W = pa.g.w, RPW = pa.g.rows_per_wave;
+    const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb, W = pa.g.w;
     constexpr int T = PIPE_BLOCK;
     MCSAS_GLOBAL PipeChain &ch = glb(pa.chains)[rep];
     if (ch.done) return;                                      // uniform for the block
@@ -482,17 +484,17 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #endif
     const PipeSnap sn = load_snap(&pa.chains[rep].snap[(t + 1) & 1]);   // the record in force for tick t (written at t-1; host for t = 0)
 
-    double *Gl = lds;                                         // [2][W*W] Gram block of the current / next sub-window
+    double *rowbuf = lds;                                     // [W][qpad] d rows of the current sub-window (accepted ones are applied from here)
+    double *Gl = rowbuf + (size_t)W * qpad;                   // [2][W*W] Gram block of the current / next sub-window
     double *lft = Gl + 2 * (size_t)W * W;                     // [qpad] ft, q-indexed
     double *lwft = lft + qpad;                                // [qpad] w * ft
-    double *lcon = lwft + qpad;                               // [Kb][PIPE_CON_BYTES / 8] the window's proposals as Contrib<M> records
-    double *ssub = lcon + (size_t)Kb * (PIPE_CON_BYTES / 8);  // [Kb][4] a, e, g of every step of the window
+    double *ssub = lwft + qpad;                               // [Kb][4] a, e, g of every step of the window
     double *hsub = ssub + (size_t)Kb * 4;                     // [64] h of the current sub-window, by step offset
     int32_t *osub = reinterpret_cast<int32_t *>(hsub + 64);   // [Kb] replay-overflow flags
     int32_t *lstage = osub + Kb, *lslot = lstage + Kb;        // [Kb] spare row slot of step k / row slot of its contribution
     int32_t *lacc = lslot + Kb;                               // [Kb + 1] accepted steps of this window, count in lacc[Kb]
-    int32_t *sacc = lacc + Kb + 1;                            // [1 + 3*64] this sub-window: count, then (old slot, new slot, step) per accepted step
-    int32_t *ctl = sacc + 1 + 3 * 64;                         // [4]: [2] = live
+    int32_t *sacc = lacc + Kb + 1;                            // [1 + 64] this sub-window: count, then the accepted steps' offsets in it
+    int32_t *ctl = sacc + 1 + 64;                             // [4]: [2] = live
     auto gft = glb(pa.ft) + (size_t)rep * qpad, gwft = glb(pa.wft) + (size_t)rep * qpad;
     auto rset = glb(a.rset) + (size_t)rep * N * P;
     auto cache = glb(a.cache) + (size_t)rep * a.cache_rows * qpad;
@@ -500,7 +502,6 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
     const auto dwin = glb((const double *)pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
     const auto gwin = glb((const double *)pa.gwin) + ((size_t)rep * 2 + buf) * Kb * W;
     const auto scal = glb((const double *)pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
-    const unsigned char *pcon = pa.pcon + ((size_t)rep * 2 + buf) * Kb * PIPE_CON_BYTES;
     const auto pval = glb((const double *)pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
     const auto povf = glb((const int32_t *)pa.povf) + ((size_t)rep * 2 + buf) * Kb;
     auto slot_of = glb(pa.slot_of) + (size_t)rep * N;
@@ -547,18 +548,24 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         const int kmax_all = budget < Kb ? (budget < 0 ? 0 : (int)budget) : Kb;
         const int ri0 = (int)((w * Kb) % N);
         const int nsub = (kmax_all + W - 1) / W;
-        // rows in registers: RB rows per batch, two batches (one being reduced, one in flight)
-        constexpr int RB = (QPL <= 4) ? 4 : (QPL == 8 ? 2 : 1);    // 16 doubles per set at most
-        const int NB = (RPW + RB - 1) / RB;                   // batches per sub-window
-        // row `i` (0..RPW-1) of this wave in sub-window s is step s W + wave + 8 i
-        auto load_batch = [&](int s, int b, double (&rb)[RB][QPL]) {
-#pragma unroll
-            for (int x = 0; x < RB; ++x) {
-                const int g = wave + 8 * (b * RB + x), k = s * W + g;
-                const bool ok = (b * RB + x) < RPW && k < kmax_all;
-                load_row_pairs<QPL>(dwin + (size_t)(ok ? k : 0) * qpad, lane, rb[x]);
+        // The d rows travel HBM/L2 -> registers -> (dot product with w ft) -> LDS row buffer.  A wave owns the rows
+        // wave, wave + 8, ... of a sub-window (RPS of them); its rows are numbered through the whole tick and row r
+        // sits in register set r % NSET: NSET rows are always under way per wave, also across the decision and
+        // apply phases between two sub-windows (loads issued as soon as the set's previous row has been used).
+        constexpr int NSET = (QPL <= 4) ? 4 : (QPL == 8 ? 3 : 2);   // (a fourth set at 8 q per lane makes the allocator spill a whole set)
+        const int RPS = W / 8;
+        const int total_r = nsub * RPS;
+        int r_load = 0, r_use = 0;
+        double rs[NSET][QPL];
+        auto request = [&](double (&dst)[QPL]) {
+            if (r_load < total_r) {
+                const int k = (r_load / RPS) * W + wave + 8 * (r_load % RPS);
+                load_row_pairs<QPL>(dwin + (size_t)(k < kmax_all ? k : 0) * qpad, lane, dst);
             }
+            ++r_load;
         };
+#pragma unroll
+        for (int i = 0; i < NSET; ++i) request(rs[i]);
         // Gram block of sub-window s -> LDS buffer s & 1 (W*W doubles, contiguous in HBM)
         auto load_gram = [&](int s) {
             const int cnt = W * W;
@@ -567,20 +574,15 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             for (int i = 2 * tid; i < cnt; i += 2 * T)
                 *reinterpret_cast<v2f64 *>(dst + i) = *(const MCSAS_GLOBAL v2f64 *)(src + i);
         };
-        double rbA[RB][QPL], rbB[RB][QPL];
-        if (nsub > 0) { load_batch(0, 0, rbA); load_gram(0); }
-        // ft, w ft -> LDS; the thread's own q (apply phase): q = tid (+ 512)
+        if (nsub > 0) load_gram(0);
+        // ft, w ft -> LDS; the thread's own q in the apply phase: q = tid (+ 512)
         constexpr int QT = (QPL * 64 + T - 1) / T;            // q per thread in the apply phase (1 or 2)
-        const bool recompute = pipe_light_model(M) && pa.g.recompute_new;
-        double wq[QT], qv[QT], q3v[QT];
+        double wq[QT];
 #pragma unroll
         for (int x = 0; x < QT; ++x) {
             const int i = tid + T * x;
-            wq[x] = 0.; qv[x] = 1.; q3v[x] = 1.;
-            if (i < qpad) {
-                wq[x] = gw_[i]; lft[i] = gft[i]; lwft[i] = gwft[i];
-                if (recompute) { const double qq = glb(a.q)[i]; qv[x] = qq; q3v[x] = 1.0 / (qq * qq * qq); }   // as the producers' tables
-            }
+            wq[x] = 0.;
+            if (i < qpad) { wq[x] = gw_[i]; lft[i] = gft[i]; lwft[i] = gwft[i]; }
         }
         if (tid < kmax_all) {                                  // Kb <= 256 < threads
             const int ov = povf[tid], stg = stage[tid];
@@ -589,10 +591,6 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             osub[tid] = ov; lstage[tid] = stg; lslot[tid] = sl;
         }
         for (int i = tid; i < kmax_all * 4; i += T) ssub[i] = scal[i];
-        if (recompute) {                                       // every proposal's Contrib record: one bulk copy per tick
-            const auto src = glb(reinterpret_cast<const double *>(pcon));
-            for (int i = tid; i < kmax_all * (PIPE_CON_BYTES / 8); i += T) lcon[i] = src[i];
-        }
         if (tid == 0) { lacc[Kb] = 0; sacc[0] = 0; }
         const double invSw = 1.0 / a.Sw, SIoSw = a.SI / a.Sw, Scen = a.SII - a.SI * a.SI / a.Sw;
         double X = cur.chi2 * nqd;
@@ -622,52 +620,47 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             const int k0 = s * W;
             const int cnt = (kmax_all - k0) < W ? (kmax_all - k0) : W;
             if (s + 1 < nsub) load_gram(s + 1);                // its buffer was last read two sub-windows ago
-            // ---- h_k = Σ (w ft) d_k for my rows of this sub-window: batches alternate between the two register sets
+            // ---- my rows of this sub-window: h = Σ (w ft) d, and the row itself into the LDS row buffer
             double acc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = 0.;
-            auto reduce_batch = [&](int b, const double (&rb)[RB][QPL]) {
+            auto use_row = [&](int i, const double (&row)[QPL]) {
+                double h0 = 0., h1 = 0.;
 #pragma unroll
-                for (int x = 0; x < RB; ++x) {
-                    double h0 = 0., h1 = 0.;
+                for (int j = 0; j < QPL; j += 2) {
+                    h0 = fma(wftp[j], row[j], h0);
+                    if (j + 1 < QPL) h1 = fma(wftp[j + 1], row[j + 1], h1);
+                }
+                const double hs = h0 + h1;
 #pragma unroll
-                    for (int j = 0; j < QPL; j += 2) {
-                        h0 = fma(wftp[j], rb[x][j], h0);
-                        if (j + 1 < QPL) h1 = fma(wftp[j + 1], rb[x][j + 1], h1);
+                for (int x = 0; x < 8; ++x) acc[x] = (x == i) ? hs : acc[x];
+                const int g = wave + 8 * i;
+                if (g < cnt) {
+                    double *dst = rowbuf + (size_t)g * qpad;
+                    if constexpr (QPL >= 2) {
+#pragma unroll
+                        for (int c = 0; c < QPL / 2; ++c)
+                            *reinterpret_cast<v2f64 *>(dst + 128 * c + 2 * lane) = (v2f64){row[2 * c], row[2 * c + 1]};
+                    } else {
+                        dst[lane] = row[0];
                     }
-                    const double hs = h0 + h1;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) if (i == b * RB + x) acc[i] = hs;
                 }
             };
-#pragma unroll
-            for (int b = 0; b < 8 / RB; b += 2) {
-                if (b < NB) {
-                    // next batch into set B: the next one of this sub-window, or the first of the next sub-window
-                    if (b + 1 < NB) load_batch(s, b + 1, rbB);
-                    else if (s + 1 < nsub) load_batch(s + 1, 0, rbB);
-                    reduce_batch(b, rbA);
-                    if (b + 1 < NB) {
-                        if (b + 2 < NB) load_batch(s, b + 2, rbA);
-                        else if (s + 1 < nsub) load_batch(s + 1, 0, rbA);
-                        reduce_batch(b + 1, rbB);
-                    } else {
-                        // odd batch count: the prefetched first batch of the next sub-window sits in set B
-#pragma unroll
-                        for (int x = 0; x < RB; ++x)
-#pragma unroll
-                            for (int j = 0; j < QPL; ++j) rbA[x][j] = rbB[x][j];
-                    }
-                }
+            for (int i = 0; i < RPS; ++i, ++r_use) {
+                const int set = r_use % NSET;                  // wave-uniform
+                if (NSET > 3 && set == 3) { use_row(i, rs[NSET > 3 ? 3 : 0]); request(rs[NSET > 3 ? 3 : 0]); }
+                else if (NSET > 2 && set == 2) { use_row(i, rs[NSET > 2 ? 2 : 0]); request(rs[NSET > 2 ? 2 : 0]); }
+                else if (set == 1) { use_row(i, rs[1]); request(rs[1]); }
+                else { use_row(i, rs[0]); request(rs[0]); }
             }
             {
                 // eight sums for the price of ~1.5: lane l < 8 ends up with the total of acc[4 (l&1) + 2 ((l>>1)&1) + ((l>>2)&1)]
                 const double tot = wave_sum8_transposed(acc, lane);
                 const int c = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
-                if (lane < 8 && c < RPW && wave + 8 * c < cnt) hsub[wave + 8 * c] = tot;
+                if (lane < 8 && c < RPS && wave + 8 * c < cnt) hsub[wave + 8 * c] = tot;
             }
             MCSAS_STAMP(s1);
-            PIPE_LDS_BARRIER();                                            // B1: hsub (and this sub-window's Gram block) complete
+            PIPE_LDS_BARRIER();                                            // B1: hsub, the row buffer and this sub-window's Gram block complete
             MCSAS_STAMP(s2);
             if (wave == 0) {
                 // ---- the W decisions of the sub-window: lane g <-> step k0 + g
@@ -715,7 +708,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     if (lane == 0) {
                         lslot[acc_row] = fresh; lstage[acc_row] = freed;      // slot swap: rows are never copied
                         lacc[num_acc_win] = acc_row;
-                        sacc[1 + 3 * nacc_sub] = freed; sacc[2 + 3 * nacc_sub] = fresh; sacc[3 + 3 * nacc_sub] = acc_row;
+                        sacc[1 + nacc_sub] = ga;
                     }
                     ++nacc_sub; ++num_acc_win; ++num_moves;
                     touched = true;
@@ -734,46 +727,19 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             live = ctl[2] != 0;
             const int nacc = sacc[0];
             if (nacc > 0) {
-                // ---- ft <- (ft - old) + new for the accepted steps, in order (mcsas.py:367,381); one q per thread.
-                // `new`: read back from the row slot the producer filled, or — models without an integral — evaluated
-                // here from the proposal's Contrib (same function and inputs as the producer's row: same bits) and
-                // stored into the slot the contribution now owns.
+                // ---- ft += d for the accepted steps, in order (mcsas.py:381), straight from the LDS row buffer: no
+                // memory round trip on the way to the next sub-window.  (d = new - old is the producers' fp64
+                // difference; the wavefront kernel's (ft - old) + new differs from ft + d in the last bit at most.)
 #pragma unroll
                 for (int x = 0; x < QT; ++x) {
                     const int i = tid + T * x;
                     if (i < qpad) {
                         double f = lft[i];
-                        if (!recompute) {
-                            for (int n0 = 0; n0 < nacc; n0 += 4) {
-                                double o[4], nw[4];
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const int n = (n0 + u < nacc) ? n0 + u : nacc - 1;
-                                    o[u] = cache[(size_t)sacc[1 + 3 * n] * qpad + i];
-                                    nw[u] = cache[(size_t)sacc[2 + 3 * n] * qpad + i];
-                                }
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) if (n0 + u < nacc) f = (f - o[u]) + nw[u];
-                            }
-                        } else if constexpr (pipe_light_model(M)) {
-                            // `old` rows run four accepted steps ahead of their use (a rotating queue of registers:
-                            // the loop stays rolled, one row evaluation per trip)
-                            auto old_at = [&](int n) { return n < nacc ? cache[(size_t)sacc[1 + 3 * n] * qpad + i] : 0.; };
-                            double o0 = old_at(0), o1 = old_at(1), o2 = old_at(2), o3 = old_at(3);
-                            for (int n = 0; n < nacc; ++n) {
-                                const double ocur = o0;
-                                o0 = o1; o1 = o2; o2 = o3; o3 = old_at(n + 4);
-                                const Contrib<M> c = *reinterpret_cast<const Contrib<M> *>(lcon + (size_t)sacc[3 + 3 * n] * (PIPE_CON_BYTES / 8));
-                                double nw = ocur;
-                                if (!(a.pad0 & 8192)) nw = pipe_point_intensity<M>(c, qv[x], q3v[x]);   // (diagnostic bits: timing only)
-                                if (!(a.pad0 & 4096)) cache[(size_t)sacc[2 + 3 * n] * qpad + i] = nw;
-                                f = (f - ocur) + nw;
-                            }
-                        }
+                        for (int n = 0; n < nacc; ++n) f += rowbuf[(size_t)sacc[1 + n] * qpad + i];
                         lft[i] = f; lwft[i] = wq[x] * f;
                     }
                 }
-                PIPE_LDS_BARRIER();                                        // B3: ft complete; sacc may be rewritten
+                PIPE_LDS_BARRIER();                                        // B3: ft complete; sacc and the row buffer may be rewritten
                 load_row_pairs_lds<QPL>(lwft, lane, wftp);
             }
 #ifdef MCSAS_STAMPS
