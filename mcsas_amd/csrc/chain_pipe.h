@@ -102,7 +102,8 @@ __device__ __forceinline__ void store_snap(PipeSnap *p, const PipeSnap &s) {
 
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
 constexpr int PIPE_WAVES = PIPE_BLOCK / 64;
-constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
+constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;
+constexpr int PIPE_MAX_ROW_DOUBLES = 32;   // scan block: doubles per lane held in row registers (rows per wave and sub-window x q per lane)   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
 static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, PipeGeom *g) {
@@ -143,8 +144,11 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     // scan sub-window: the largest multiple of 8 that divides the producer block's rows and whose d rows fit the
     // scan block's LDS row buffer (the accepted rows are applied to ft from there, not from HBM)
     g->w = 8;
-    for (int ws = 8; ws <= 8 * rpw && ws <= 64; ws += 8)
+    for (int ws = 8; ws <= 8 * rpw && ws <= 64; ws += 8) {
+        const int rps = ws / 8;
+        if (rps == 5 || rps == 7 || rps * qpl > PIPE_MAX_ROW_DOUBLES) continue;   // the kernels instantiate 1, 2, 3, 4, 6, 8 rows per wave
         if ((8 * rpw) % ws == 0 && sizeof(double) * (size_t)ws * qpad <= 96 * 1024) g->w = ws;
+    }
     g->sub_per_block = 8 * rpw / g->w;
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
@@ -467,7 +471,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
 
 // ------------------------------------------------------------------------------------ scanner
 // LDS: two Gram blocks, ft and w*ft, the window's scalars, h of the current sub-window, flags and slot tables
-template <int M, int QPL>
+template <int QPL, int RPS>                                    // RPS = rows per wave and sub-window (W / 8), compile time: see `request`
 __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds, int rep, int t, int stop_now) {
     static_assert(PIPE_GRAM_TILES_PER_ROUND * 256 == PIPE_BLOCK, "Gram reduction maps one thread to one tile element");
     const ChainArgs &a = pa.c;
@@ -549,32 +553,45 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         const int ri0 = (int)((w * Kb) % N);
         const int nsub = (kmax_all + W - 1) / W;
         // The d rows travel HBM/L2 -> registers -> (dot product with w ft) -> LDS row buffer.  A wave owns the rows
-        // wave, wave + 8, ... of a sub-window (RPS of them); its rows are numbered through the whole tick and row r
-        // sits in register set r % NSET: NSET rows are always under way per wave, also across the decision and
-        // apply phases between two sub-windows (loads issued as soon as the set's previous row has been used).
-        constexpr int NSET = (QPL <= 4) ? 4 : (QPL == 8 ? 3 : 2);   // (a fourth set at 8 q per lane makes the allocator spill a whole set)
-        const int RPS = W / 8;
+        // wave, wave + 8, ... of a sub-window (RPS of them).
+        // Row i of EVERY sub-window sits in register set i, and the row for the next sub-window is requested as soon as
+        // the set has been used: RPS rows per wave are under way all the time, also across the decision and apply
+        // phases.  RPS is a template parameter because a load whose target depends on a run-time choice (or sits
+        // under a condition) becomes a load into scratch registers, a wait and a copy at the join: no prefetch.
         const int total_r = nsub * RPS;
-        int r_load = 0, r_use = 0;
-        double rs[NSET][QPL];
+        int r_load = 0;
+        double rs[RPS][QPL];
         auto request = [&](double (&dst)[QPL]) {
-            if (r_load < total_r) {
-                const int k = (r_load / RPS) * W + wave + 8 * (r_load % RPS);
-                load_row_pairs<QPL>(dwin + (size_t)(k < kmax_all ? k : 0) * qpad, lane, dst);
-            }
+            const int rr = r_load < total_r ? r_load : 0;      // (past the end: row 0 again, never used)
+            const int k = (rr / RPS) * W + wave + 8 * (rr % RPS);
+            load_row_pairs<QPL>(dwin + (size_t)(k < kmax_all ? k : 0) * qpad, lane, dst);
             ++r_load;
         };
 #pragma unroll
-        for (int i = 0; i < NSET; ++i) request(rs[i]);
-        // Gram block of sub-window s -> LDS buffer s & 1 (W*W doubles, contiguous in HBM)
-        auto load_gram = [&](int s) {
-            const int cnt = W * W;
+        for (int i = 0; i < RPS; ++i) request(rs[i]);
+        // Gram block of sub-window s -> LDS buffer s & 1 (W*W doubles, contiguous in HBM): the loads are issued at the
+        // top of the previous sub-window and parked in registers, the LDS stores follow behind that sub-window's rows
+        // (a load-store copy loop would drain every outstanding row load at its first store)
+        constexpr int NG = (RPS * RPS * 64 / 2 + T - 1) / T;   // 16-byte pieces per thread (W*W / 2 pieces in all)
+        v2f64 gtmp[NG];
+        auto gram_fetch = [&](int s) {
             const auto src = gwin + (size_t)s * W * W;
-            double *dst = Gl + (size_t)(s & 1) * W * W;
-            for (int i = 2 * tid; i < cnt; i += 2 * T)
-                *reinterpret_cast<v2f64 *>(dst + i) = *(const MCSAS_GLOBAL v2f64 *)(src + i);
+#pragma unroll
+            for (int x = 0; x < NG; ++x) {
+                int i = 2 * (tid + T * x);
+                if (i > W * W - 2) i = W * W - 2;              // (clamped, not skipped: see `request`)
+                gtmp[x] = *(const MCSAS_GLOBAL v2f64 *)(src + i);
+            }
         };
-        if (nsub > 0) load_gram(0);
+        auto gram_store = [&](int s) {
+            double *dst = Gl + (size_t)(s & 1) * W * W;
+#pragma unroll
+            for (int x = 0; x < NG; ++x) {
+                const int i = 2 * (tid + T * x);
+                if (i < W * W) *reinterpret_cast<v2f64 *>(dst + i) = gtmp[x];
+            }
+        };
+        if (nsub > 0) { gram_fetch(0); gram_store(0); }
         // ft, w ft -> LDS; the thread's own q in the apply phase: q = tid (+ 512)
         constexpr int QT = (QPL * 64 + T - 1) / T;            // q per thread in the apply phase (1 or 2)
         double wq[QT];
@@ -619,7 +636,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             MCSAS_STAMP(s0);
             const int k0 = s * W;
             const int cnt = (kmax_all - k0) < W ? (kmax_all - k0) : W;
-            if (s + 1 < nsub) load_gram(s + 1);                // its buffer was last read two sub-windows ago
+            gram_fetch(s + 1 < nsub ? s + 1 : s);              // (its LDS buffer was last read two sub-windows ago)
             // ---- my rows of this sub-window: h = Σ (w ft) d, and the row itself into the LDS row buffer
             double acc[8];
 #pragma unroll
@@ -646,19 +663,15 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     }
                 }
             };
-            for (int i = 0; i < RPS; ++i, ++r_use) {
-                const int set = r_use % NSET;                  // wave-uniform
-                if (NSET > 3 && set == 3) { use_row(i, rs[NSET > 3 ? 3 : 0]); request(rs[NSET > 3 ? 3 : 0]); }
-                else if (NSET > 2 && set == 2) { use_row(i, rs[NSET > 2 ? 2 : 0]); request(rs[NSET > 2 ? 2 : 0]); }
-                else if (set == 1) { use_row(i, rs[1]); request(rs[1]); }
-                else { use_row(i, rs[0]); request(rs[0]); }
-            }
+#pragma unroll
+            for (int i = 0; i < RPS; ++i) { use_row(i, rs[i]); request(rs[i]); }
             {
                 // eight sums for the price of ~1.5: lane l < 8 ends up with the total of acc[4 (l&1) + 2 ((l>>1)&1) + ((l>>2)&1)]
                 const double tot = wave_sum8_transposed(acc, lane);
                 const int c = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
                 if (lane < 8 && c < RPS && wave + 8 * c < cnt) hsub[wave + 8 * c] = tot;
             }
+            gram_store(s + 1);                                 // read at the earliest after B1 of the next sub-window
             MCSAS_STAMP(s1);
             PIPE_LDS_BARRIER();                                            // B1: hsub, the row buffer and this sub-window's Gram block complete
             MCSAS_STAMP(s2);
@@ -876,7 +889,15 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
     const PipeArgs &pa = *pap;
     const int R = pa.c.n_reps, b = blockIdx.x, t = tick;
     if (b < R) {
-        if (t >= 0) pipe_scan_block<M, QPL>(pa, lds, b, t, stop_now);
+        if (t >= 0) {
+            // rows per wave and sub-window: uniform for the launch; the host only picks combinations instantiated here
+            switch (pa.g.w >> 3) {
+#define PIPE_SCAN_CASE(r) case r: if constexpr (r * QPL <= PIPE_MAX_ROW_DOUBLES) pipe_scan_block<QPL, r>(pa, lds, b, t, stop_now); break;
+                PIPE_SCAN_CASE(1) PIPE_SCAN_CASE(2) PIPE_SCAN_CASE(3) PIPE_SCAN_CASE(4) PIPE_SCAN_CASE(6) PIPE_SCAN_CASE(8)
+#undef PIPE_SCAN_CASE
+                default: break;
+            }
+        }
     } else {
         // chain-major block -> (chain, sub-window) map: round-robin dispatch then spreads every chain's blocks
         // over the 8 XCDs.  The XCD-aware alternative (diagnostic bit 128: chain r's producer blocks on block ids
