@@ -68,6 +68,7 @@ struct PipeGeom {
     int32_t qpl;
     int32_t gram_off;             // producer LDS: offset (doubles) of the Gram reduction buffer
     int32_t sub_per_block;        // scan sub-windows per producer block (8 * rows_per_wave / w)
+    int32_t split_roles, pad1;    // producer block: waves 0..3 evaluate rows, waves 4..7 the Gram blocks behind them
     uint64_t prod_lds, scan_lds;
 };
 
@@ -106,7 +107,7 @@ constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;
 constexpr int PIPE_MAX_ROW_DOUBLES = 32;   // scan block: doubles per lane held in row registers (rows per wave and sub-window x q per lane)   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
-static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, PipeGeom *g) {
+static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int split_req, PipeGeom *g) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
@@ -153,7 +154,16 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
     g->gram_off = 4 * qpad + tab_doubles;
-    g->prod_lds = sizeof(double) * ((size_t)g->gram_off + (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256);
+    // Rows without an integral are pure fp64 vector work, the Gram blocks pure MFMA work: four row waves (one per
+    // SIMD) and four Gram waves one sub-window behind them keep both pipes busy at once.  Rows with an integral keep
+    // all eight waves on rows (their long dependent chains need two waves per SIMD).
+    g->split_roles = (heavy_rows || !split_req) ? 0 : 1;
+    {
+        const int tg = (g->w + 15) / 16, nt = tg * (tg + 1) / 2;
+        size_t red = (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256;
+        if (g->split_roles) red = (size_t)g->sub_per_block * 4 * nt * 256;
+        g->prod_lds = sizeof(double) * ((size_t)g->gram_off + 16 + red);    // 16 doubles: hand-off counters
+    }
     g->scan_waves = PIPE_WAVES;
     // scan block LDS: the sub-window's d rows, two Gram blocks (double buffer), ft and w*ft, the window's scalars, h of
     // the sub-window, flags / slot tables / accepted lists
@@ -201,14 +211,17 @@ __device__ __forceinline__ void load_row_pairs_lds(const double *row, int lane, 
 // contiguous bytes, so a 128-byte line is consumed by two consecutive loads instead of lingering in L1.
 // The eight partial tiles are then summed in wave order through LDS (deterministic) and written to
 // gout[a][k], a, k < W.
-template <int QPL, int T>                                     // T = 16-row groups of the sub-window (1..4), compile time: straight-line MFMA code
-__device__ __forceinline__ void pipe_prod_gram_t(const MCSAS_GLOBAL double *drows, int qpad, int W, int nvalid, const double *lw,
-                                                 double *gred, MCSAS_GLOBAL double *gout) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// The MFMA part: this wave's share (q slice gw of NWV) of every upper-triangular tile.  T = 16-row groups of the
+// sub-window (1..4), compile time: straight-line MFMA code.
+template <int QPL, int T, int NWV>
+__device__ __forceinline__ void pipe_gram_mfma(const MCSAS_GLOBAL double *drows, int qpad, int nvalid, const double *lw, int gw,
+                                               v4f64 (&acc)[T * (T + 1) / 2]) {
+    const int lane = threadIdx.x & 63;
     const int m = lane & 15, kk = lane >> 4;
     constexpr int NT = T * (T + 1) / 2;                       // upper-triangular tiles (gi <= gj), row-major
-    const int qs = wave * (8 * QPL) + kk * 2;
-    v4f64 acc[NT];
+    constexpr int SLICE = 64 * QPL / NWV;                     // q per wave; a load covers 8 of them (two per k-slot)
+    static_assert(SLICE >= 8, "too many waves for this q count");
+    const int qs = gw * SLICE + kk * 2;
 #pragma unroll
     for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0., 0., 0., 0.};
     const MCSAS_GLOBAL double *rowp[T];
@@ -228,12 +241,12 @@ __device__ __forceinline__ void pipe_prod_gram_t(const MCSAS_GLOBAL double *drow
     };
     fetch(0, nxt, wnx);
 #pragma unroll
-    for (int s = 0; s < 2 * QPL; s += 2) {
+    for (int s = 0; s < SLICE / 4; s += 2) {
         v2f64 av[T], bv[T];
         const v2f64 wv = wnx;
 #pragma unroll
         for (int gi = 0; gi < T; ++gi) av[gi] = rowok[gi] ? nxt[gi] : (v2f64){0., 0.};
-        if (s + 2 < 2 * QPL) fetch(s + 2, nxt, wnx);
+        if (s + 2 < SLICE / 4) fetch(s + 2, nxt, wnx);
 #pragma unroll
         for (int gi = 0; gi < T; ++gi) bv[gi] = av[gi] * wv;
         int ti = 0;
@@ -246,6 +259,29 @@ __device__ __forceinline__ void pipe_prod_gram_t(const MCSAS_GLOBAL double *drow
                 ++ti;
             }
     }
+}
+
+// tile number -> (row group, column group) of the upper triangle, and the store of one summed element
+template <int T>
+__device__ __forceinline__ void pipe_gram_store(int tsel, int idx, double sum, int W, MCSAS_GLOBAL double *gout) {
+    int ti = 0, tgi = 0, tgj = 0;
+#pragma unroll
+    for (int gi = 0; gi < T; ++gi)
+#pragma unroll
+        for (int gj = gi; gj < T; ++gj) { if (ti == tsel) { tgi = gi; tgj = gj; } ++ti; }
+    const int i = 4 * (idx >> 6) + ((idx & 63) >> 4), j = idx & 15;   // result register r of lane l holds D[4 r + l / 16][l % 16]
+    const int ar = 16 * tgi + i, kc = 16 * tgj + j;
+    if (ar < W && kc < W) gout[(size_t)ar * W + kc] = sum;
+}
+
+// All eight waves of the block, partial tiles summed in wave order through LDS between two barriers.
+template <int QPL, int T>
+__device__ __forceinline__ void pipe_prod_gram_t(const MCSAS_GLOBAL double *drows, int qpad, int W, int nvalid, const double *lw,
+                                                 double *gred, MCSAS_GLOBAL double *gout) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NT = T * (T + 1) / 2;
+    v4f64 acc[NT];
+    pipe_gram_mfma<QPL, T, PIPE_WAVES>(drows, qpad, nvalid, lw, wave, acc);
     // cross-wave sum, PIPE_GRAM_TILES_PER_ROUND tiles per round
     constexpr int TPR = PIPE_GRAM_TILES_PER_ROUND;
 #pragma unroll
@@ -264,14 +300,7 @@ __device__ __forceinline__ void pipe_prod_gram_t(const MCSAS_GLOBAL double *drow
                 double sum = 0.;
 #pragma unroll
                 for (int v = 0; v < PIPE_WAVES; ++v) sum += gred[(size_t)(v * TPR + u) * 256 + idx];
-                int ti = 0, tgi = 0, tgj = 0;
-#pragma unroll
-                for (int gi = 0; gi < T; ++gi)
-#pragma unroll
-                    for (int gj = gi; gj < T; ++gj) { if (ti == tsel) { tgi = gi; tgj = gj; } ++ti; }
-                const int i = 4 * (idx >> 6) + ((idx & 63) >> 4), j = idx & 15;
-                const int ar = 16 * tgi + i, kc = 16 * tgj + j;
-                if (ar < W && kc < W) gout[(size_t)ar * W + kc] = sum;
+                pipe_gram_store<T>(tsel, idx, sum, W, gout);
             }
         }
         if (r0 + TPR < NT) PIPE_LDS_BARRIER();
@@ -286,6 +315,56 @@ __device__ __forceinline__ void pipe_prod_gram(const MCSAS_GLOBAL double *drows,
         case 2: pipe_prod_gram_t<QPL, 2>(drows, qpad, W, nvalid, lw, gred, gout); break;
         case 3: pipe_prod_gram_t<QPL, 3>(drows, qpad, W, nvalid, lw, gred, gout); break;
         default: pipe_prod_gram_t<QPL, 4>(drows, qpad, W, nvalid, lw, gred, gout); break;
+    }
+}
+
+
+// Waves 4..7 of a role-split producer block (gv = wave - 4): same tiles, the q range split four ways, and no
+// workgroup barrier — the row waves are busy with the next sub-window.  Each Gram wave parks its partial tiles in
+// LDS and counts itself in; when all four are in, every wave sums a quarter of the elements in wave order
+// (deterministic) and stores them.  Spins are bounded: a hand-off that never comes sets *timeout instead of hanging.
+constexpr int PIPE_SPIN_LIMIT = 1 << 22;
+__device__ __forceinline__ bool pipe_spin_until(int32_t *word, int target) {
+    for (int n = 0; n < PIPE_SPIN_LIMIT; ++n) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+template <int QPL, int T>
+__device__ __forceinline__ bool pipe_gram_flag_t(const MCSAS_GLOBAL double *drows, int qpad, int W, int nvalid, const double *lw,
+                                                 double *gred, int32_t *arrived, MCSAS_GLOBAL double *gout, int gv) {
+    const int lane = threadIdx.x & 63;
+    constexpr int NT = T * (T + 1) / 2;
+    v4f64 acc[NT];
+    pipe_gram_mfma<QPL, T, 4>(drows, qpad, nvalid, lw, gv, acc);
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gred[((size_t)(gv * NT + ti) * 4 + r) * 64 + lane] = acc[ti][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) atomicAdd(arrived, 1);
+    if (!pipe_spin_until(arrived, 4)) return false;
+    asm volatile("" ::: "memory");
+    // NT * 256 elements, a quarter per wave: element e = gv * (NT * 64) + n * 64 + lane
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int e = gv * (NT * 64) + n * 64 + lane, tsel = e >> 8, idx = e & 255;
+        double sum = 0.;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sum += gred[(size_t)(v * NT + tsel) * 256 + idx];
+        pipe_gram_store<T>(tsel, idx, sum, W, gout);
+    }
+    return true;
+}
+template <int QPL>
+__device__ __forceinline__ bool pipe_gram_flag(const MCSAS_GLOBAL double *drows, int qpad, int W, int nvalid, const double *lw,
+                                               double *gred, int32_t *arrived, MCSAS_GLOBAL double *gout, int gv) {
+    switch ((W + 15) >> 4) {                                   // uniform for the launch
+        case 1: return pipe_gram_flag_t<QPL, 1>(drows, qpad, W, nvalid, lw, gred, arrived, gout, gv);
+        case 2: return pipe_gram_flag_t<QPL, 2>(drows, qpad, W, nvalid, lw, gred, arrived, gout, gv);
+        case 3: return pipe_gram_flag_t<QPL, 3>(drows, qpad, W, nvalid, lw, gred, arrived, gout, gv);
+        default: return pipe_gram_flag_t<QPL, 4>(drows, qpad, W, nvalid, lw, gred, arrived, gout, gv);
     }
 }
 
@@ -304,6 +383,8 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
         lq[i] = qq; lw[i] = glb(a.w)[i]; lwI[i] = glb(a.wI)[i]; lq3[i] = 1.0 / (qq * qq * qq);
     }
     Contrib<M>::fill_table(a.model, tab, tid, PIPE_BLOCK);
+    int32_t *handoff = reinterpret_cast<int32_t *>(lds + pa.g.gram_off);   // [0] row waves done per sub-window, [1 + ss] Gram waves in
+    if (tid < 32) handoff[tid] = 0;
     __syncthreads();
     const QTables qt = make_qtables<M>(a.model, lq, lq3, tab);
     auto rset = glb(a.rset) + (size_t)rep * N * P;
@@ -355,6 +436,109 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     }
 
     if (a.pad0 & 16) return;                                  // diagnostic: no window rows
+    if (pa.g.split_roles) {
+        // ---- role split (rows without an integral): waves 0..3 evaluate the block's rows sub-window by sub-window,
+        // waves 4..7 follow one sub-window behind with its Gram block; hand-offs through LDS counters, no barrier
+        const int W = pa.g.w, nsb = pa.g.sub_per_block, RW = W >> 2, BR = nsb * W;     // RW rows per row wave and sub-window
+        const int buf = t & 1;
+        const int64_t w = (int64_t)t - sn.t_init - 1;
+        const int64_t sb0 = w * Kb + (int64_t)by * BR;                               // global step of the block's first row
+        auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
+        if (wave < 4) {
+            auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
+            auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
+            auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
+            const int nmine = nsb * RW;                                              // my rows (<= 16), lane l <-> my l-th row
+            const int lrow = (lane / RW) * W + wave * RW + (lane % RW);               // its offset in the block
+            double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+            int pov = 0, my_oslot = 0, my_sslot = 0;
+            {
+                const int64_t sl = sb0 + lrow;
+#pragma unroll
+                for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+                    if (p < P) {
+                        double u = 0.5;
+                        if (lane < nmine && sl < a.max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
+                        prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
+                    }
+                if (lane < nmine) {
+                    const int r = (int)((sb0 + lrow) % N);
+                    my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + by * BR + lrow];
+                }
+            }
+            Contrib<M> prop;
+            prop.prepare(a.model, prow);
+            double onext[QPL];
+            {
+                const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) onext[j] = orow0[WAVE * j];
+            }
+            for (int l = 0; l < nmine; ++l) {
+                const int bl = __builtin_amdgcn_readfirstlane(l);
+                const int kl = (l / RW) * W + wave * RW + (l % RW), k = by * BR + kl;
+                const Contrib<M> cnew = prop.bcast(bl);
+                const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
+                double d[QPL], nwv[QPL];
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) d[j] = onext[j];
+                {
+                    const int bn = __builtin_amdgcn_readfirstlane(l + 1 < nmine ? l + 1 : l);
+                    const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bn) * qpad + lane;
+#pragma unroll
+                    for (int j = 0; j < QPL; ++j) onext[j] = orow[WAVE * j];
+                }
+                if (sb0 + kl < a.max_iter) {                                          // uniform
+                    const auto nrow = cache + (size_t)sslot * qpad + lane;
+                    const auto dr = dwin + (size_t)k * qpad + lane;
+                    RowEval<M, QPL>::run(cnew, qt, lane, nwv);
+                    double s1 = 0., s2 = 0., s3 = 0.;
+#pragma unroll
+                    for (int j = 0; j < QPL; ++j) {
+                        const int iq = lane + WAVE * j;
+                        nrow[WAVE * j] = nwv[j];
+                        d[j] = nwv[j] - d[j];
+                        dr[WAVE * j] = d[j];
+                        const double wd = lw[iq] * d[j];
+                        s1 += wd; s2 += lwI[iq] * d[j]; s3 += wd * d[j];
+                    }
+                    wave_sum3(s1, s2, s3);
+                    if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
+#pragma unroll
+                    for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+                        if (p < P) {
+                            const double v = readlane_f64(prow[p], bl);
+                            if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
+                        }
+                    const int ov = __builtin_amdgcn_readlane(pov, bl);
+                    if (lane == 0) povf[k] = ov;
+                }
+                if ((l % RW) == RW - 1) {
+                    // my rows of this sub-window are written: count this wave in for the Gram waves
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) atomicAdd(&handoff[0], 1);
+                }
+            }
+        } else if (!(a.pad0 & 64)) {
+            const int gv = wave - 4;
+            double *gred0 = lds + pa.g.gram_off + 16;
+            const int tg = (W + 15) >> 4, nt = tg * (tg + 1) / 2;
+            bool ok = true;
+            for (int ss = 0; ss < nsb && ok; ++ss) {
+                const int sub = by * nsb + ss;
+                const int64_t left = a.max_iter - (w * Kb + (int64_t)sub * W);
+                const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
+                ok = pipe_spin_until(&handoff[0], 4 * (ss + 1));                      // the four row waves have stored sub-window ss
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (ok && nvalid > 1)
+                    ok = pipe_gram_flag<QPL>(dwin + (size_t)sub * W * qpad, qpad, W, nvalid, lw, gred0 + (size_t)ss * 4 * nt * 256,
+                                             &handoff[1 + ss], glb(pa.gwin) + (((size_t)rep * 2 + buf) * Kb + (size_t)sub * W) * W, gv);
+            }
+            if (!ok && lane == 0) atomicOr(&pa.chains[rep].overflow, 2);              // reported as an error by the host, never a hang
+        }
+        return;
+    }
+
     MCSAS_STAMP_DECL(pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0);
     MCSAS_STAMP(pp0);
     // ---- window w of the attempt: this wave's rows k = gw*rpw .. +rpw-1, one proposal per lane
@@ -452,7 +636,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
             const int64_t left = a.max_iter - (w * Kb + (int64_t)sub * W);
             const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
             if (nvalid > 1)
-                pipe_prod_gram<QPL>(dwin + (size_t)sub * W * qpad, qpad, W, nvalid, lw, lds + pa.g.gram_off,
+                pipe_prod_gram<QPL>(dwin + (size_t)sub * W * qpad, qpad, W, nvalid, lw, lds + pa.g.gram_off + 16,
                                     glb(pa.gwin) + (((size_t)rep * 2 + buf) * Kb + (size_t)sub * W) * W);
             if (ss + 1 < nsb) PIPE_LDS_BARRIER();             // the reduction buffer is reused
         }

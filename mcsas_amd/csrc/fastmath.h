@@ -88,6 +88,46 @@ MCSAS_HD void sincos_core(double x, double *sn, double *cs) {
     *cs = ((q + 1) & 2) ? -co : co;
 }
 
+// sincos_core over N independent arguments, written stage by stage so that the N dependent chains are issued
+// interleaved (one chain after the other runs at the fp64 pipe's latency, not its issue rate).  The operations
+// and their order per element are exactly sincos_core's: the results are bit-identical.
+template <int N>
+MCSAS_HD void sincos_core_n(const double (&x)[N], double (&sn)[N], double (&cs)[N]) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double P1 = 1.57079632679489655800e+00;
+    const double P2 = 6.12323399573676603587e-17;
+    double n[N], r[N], r2[N], ps[N], pc[N];
+    int q[N];
+#if defined(__HIPCC__)
+#define MCSAS_UNROLL _Pragma("unroll")
+#else
+#define MCSAS_UNROLL
+#endif
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) n[i] = rint(x[i] * TWO_OVER_PI);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) r[i] = fma(-n[i], P1, x[i]);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) r[i] = fma(-n[i], P2, r[i]);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) { q[i] = (int)n[i]; r2[i] = r[i] * r[i]; }
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) ps[i] = fma(r2[i], 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) pc[i] = fma(r2[i], -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) ps[i] = fma(r2[i], ps[i], 2.75573137070700676789e-06);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) pc[i] = fma(r2[i], pc[i], -2.75573143513906633035e-07);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) ps[i] = fma(r2[i], ps[i], -1.98412698298579493134e-04);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) pc[i] = fma(r2[i], pc[i], 2.48015872894767294178e-05);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) ps[i] = fma(r2[i], ps[i], 8.33333333332248946124e-03);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) pc[i] = fma(r2[i], pc[i], -1.38888888888741095749e-03);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) ps[i] = fma(r2[i], ps[i], -1.66666666666666324348e-01);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) pc[i] = fma(r2[i], pc[i], 4.16666666666666019037e-02);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) {
+        const double s = fma(r[i] * r2[i], ps[i], r[i]);
+        const double c = fma(r2[i] * r2[i], pc[i], fma(-0.5, r2[i], 1.0));
+        const double so = (q[i] & 1) ? c : s;
+        const double co = (q[i] & 1) ? s : c;
+        sn[i] = (q[i] & 2) ? -so : so;
+        cs[i] = ((q[i] + 1) & 2) ? -co : co;
+    }
+#undef MCSAS_UNROLL
+}
+
 // Bessel J1, the Cephes algorithm (the one behind scipy.special.j1 that the reference calls,
 // cylindersisotropic.py:74, kholodenko.py:43): rational approximation on [0, 5], Hankel asymptotic
 // form with rational P, Q beyond.  Same coefficients, so the values track scipy's to ~1e-17 absolute;
