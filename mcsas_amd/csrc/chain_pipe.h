@@ -307,6 +307,7 @@ __device__ __forceinline__ void pipe_prod_gram_t(const MCSAS_GLOBAL double *drow
     }
 }
 
+
 template <int QPL>
 __device__ __forceinline__ void pipe_prod_gram(const MCSAS_GLOBAL double *drows, int qpad, int W, int nvalid, const double *lw,
                                                double *gred, MCSAS_GLOBAL double *gout) {
@@ -374,13 +375,22 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int WPB = PIPE_BLOCK / 64;
     const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb;
+    // the data tables do not depend on the chain's schedule record: both round trips run side by side
+    constexpr int QTB = (QPL * 64 + PIPE_BLOCK - 1) / PIPE_BLOCK;
+    double tq[QTB], tw[QTB], twI[QTB];
+#pragma unroll
+    for (int x = 0; x < QTB; ++x) {
+        const int i = tid + PIPE_BLOCK * x < qpad ? tid + PIPE_BLOCK * x : 0;
+        tq[x] = glb(a.q)[i]; tw[x] = glb(a.w)[i]; twI[x] = glb(a.wI)[i];
+    }
     const PipeSnap sn = load_snap(&pa.chains[rep].snap[t & 1]);
     if (!sn.alive || t < sn.t_init) return;
 
     double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
-    for (int i = tid; i < qpad; i += PIPE_BLOCK) {
-        const double qq = glb(a.q)[i];
-        lq[i] = qq; lw[i] = glb(a.w)[i]; lwI[i] = glb(a.wI)[i]; lq3[i] = 1.0 / (qq * qq * qq);
+#pragma unroll
+    for (int x = 0; x < QTB; ++x) {
+        const int i = tid + PIPE_BLOCK * x;
+        if (i < qpad) { lq[i] = tq[x]; lw[i] = tw[x]; lwI[i] = twI[x]; lq3[i] = 1.0 / (tq[x] * tq[x] * tq[x]); }
     }
     Contrib<M>::fill_table(a.model, tab, tid, PIPE_BLOCK);
     int32_t *handoff = reinterpret_cast<int32_t *>(lds + pa.g.gram_off);   // [0] row waves done per sub-window, [1 + ss] Gram waves in
@@ -630,6 +640,8 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     __syncthreads();
     MCSAS_STAMP(pp2);
     {
+        // (one pass over both sub-windows with six accumulators and a single run of reduction rounds was measured:
+        // no faster than one call per sub-window)
         const int W = pa.g.w, nsb = pa.g.sub_per_block;       // the block's rows are nsb scan sub-windows of W steps
         for (int ss = 0; ss < nsb; ++ss) {
             const int sub = by * nsb + ss;                    // sub-window index within the window

@@ -147,7 +147,10 @@ __global__ __launch_bounds__(64) void chain_wave_kernel(const ChainArgs a) {
                 RowEval<M, QPL>::run(cnew, qt, lane, inew);
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
-                    test[j] = (ft[j] - test[j]) + inew[j];                         // mcsas.py:367
+                    // mcsas.py:367 has (ft - old) + new; every execution mode here adds the fp64 difference d = new - old
+                    // instead (the workgroup and pipeline kernels carry d rows), so that ft is the SAME number in all
+                    // three modes — at most one ulp per accepted move away from the reference's order
+                    test[j] = ft[j] + (inew[j] - test[j]);
                     double wt = lw[lane + WAVE * j] * test[j];
                     s1 += wt; s2 += wt * test[j]; s3 += lwI[lane + WAVE * j] * test[j];
                 }

@@ -18,6 +18,9 @@ void *CAT(mcsas_wave_kernel_m, MCSAS_M)(int qpl, bool cache) {
         case 4: return pick<4>(cache);
         case 8: return pick<8>(cache);
         case 16: return pick<16>(cache);
+        // nq up to 2048 / 4096 (un-binned data files, nBin = 0): cached rows only — the host forces the cache on
+        case 32: return cache ? (void *)chain_wave_kernel<MCSAS_M, 32, true> : nullptr;
+        case 64: return cache ? (void *)chain_wave_kernel<MCSAS_M, 64, true> : nullptr;
         default: return nullptr;
     }
 }

@@ -449,7 +449,10 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     // q slots per lane: power of two so the kernels are fully unrolled
     int qpl = 1;
     while (qpl * WAVE < p->nq) qpl *= 2;
-    if (qpl > 16) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 1024 is not supported", p->nq); }
+    // up to 1024 q-points every execution mode has kernels (q slots per lane 1..16); 1025..4096 (un-binned data,
+    // nBin = 0) run one wavefront per chain with 32 / 64 slots per lane and cached rows
+    if (qpl > 64) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 4096 is not supported", p->nq); }
+    const bool wide_q = qpl > 16;
     const int qpad = qpl * WAVE;
     rc = pl->smear.upload(p, qpad, &margs);
     if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
@@ -474,6 +477,13 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
             else mode = MCSAS_EXEC_WAVE;
         }
+    }
+    if (wide_q) {
+        if (mode != MCSAS_EXEC_AUTO && mode != MCSAS_EXEC_WAVE && p->exec_mode != MCSAS_EXEC_AUTO) {
+            mcsas_hip_plan_destroy(pl);
+            return fail(MCSAS_EINVAL, "nq %d > 1024 runs one wavefront per chain only (exec_mode %d asked)", p->nq, p->exec_mode);
+        }
+        mode = MCSAS_EXEC_WAVE;
     }
     if (mode == MCSAS_EXEC_WORKGROUP && waves < 2) waves = WG_MAX_WAVES;
     if (mode != MCSAS_EXEC_WORKGROUP) waves = 1;
@@ -515,11 +525,11 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     }
     size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
     int use_cache = p->cache_intensities;
-    if (use_cache < 0 || mode != MCSAS_EXEC_WAVE) {
+    if (use_cache < 0 || mode != MCSAS_EXEC_WAVE || wide_q) {
         size_t fr = 0, tot = 0;
         PCHK(hipMemGetInfo(&fr, &tot));
         use_cache = cache_bytes < fr / 2;
-        if (mode != MCSAS_EXEC_WAVE && !use_cache) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_ENOMEM, "intensity cache (%zu MB) does not fit", cache_bytes >> 20); }
+        if ((mode != MCSAS_EXEC_WAVE || wide_q) && !use_cache) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_ENOMEM, "intensity cache (%zu MB) does not fit", cache_bytes >> 20); }
     }
     pl->use_cache = use_cache;
     if (use_cache) PCHK(hipMalloc(&pl->d_cache, cache_bytes));

@@ -319,6 +319,9 @@ def test_full_size_properties_other_configs(name):
 EDGE = [  # (nq, n_contrib, max_iter, reps)
     (64, 40, 130, 3), (65, 33, 97, 2), (7, 16, 50, 2), (130, 2, 40, 2), (512, 1, 10, 2), (100, 50, 0, 2),
     (300, 200, 700, 5), (1024, 64, 90, 2),
+    # more than 1024 q-points (un-binned data files, nBin = 0: the reference takes any data.count, mcsas.py:210): one
+    # wavefront per chain with 32 / 64 q slots per lane; the workgroup and pipeline modes refuse these shapes
+    (1500, 40, 120, 2), (2048, 33, 70, 2), (3000, 24, 50, 1), (4096, 20, 40, 1),
 ]
 
 
@@ -709,3 +712,27 @@ def test_no_active_parameter_returns_the_model_intensity():
     np.testing.assert_allclose(r.fit[:, 0], want, rtol=1e-9)
     with pytest.raises(mcsas_amd._lib.McSASHipError):
         engine.Plan(m.setup(), q, I, sig, st)
+
+
+def test_more_than_4096_q_points_is_refused_loudly():
+    q, I, sig = _synthetic(4100)
+    m, _ = make_models("sphere", [np.pi / q.max()], [np.pi / q.min()])
+    st = engine.Settings(n_contrib=20, n_reps=1, max_iter=10, conv_crit=0.0, max_retries=0)
+    with pytest.raises(mcsas_amd._lib.McSASHipError) as e:
+        engine.analyse(m.setup(), q, I, sig, st)
+    assert e.value.code == -1 and "4096" in str(e.value)
+
+
+def test_role_split_producer_blocks_replay_the_reference():
+    """The alternative producer layout of the pipeline (four row waves + four Gram waves per block with LDS
+    hand-offs, tuning bit 16 of the diagnostic word) is kept for measurements: it replays the reference's
+    512 q x 400 contribution chain like the default layout does.  (Its Gram blocks are summed over four q ranges
+    instead of eight, so a free-running chain may take a different turn at a numerically tied step — replacing one
+    negligible sphere by another moves chi² by less than its rounding error — which is why the comparison is with
+    the reference, not with the default layout.)"""
+    g, m, spec, st, ost = traj_setup("g4_sphere_q512_fixed.npz")
+    st.exec_mode, st.debug_flags = engine.EXEC_PIPELINE, 1 << 16
+    res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st, replay=g["stream"][None, :])
+    assert res.num_iter[0] == int(g["res_num_iter"]) and res.num_moves[0] == int(g["res_num_moves"])
+    np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
+    np.testing.assert_allclose(res.chisq[0], float(g["res_conval"]), rtol=1e-7)
