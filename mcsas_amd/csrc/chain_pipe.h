@@ -68,7 +68,8 @@ struct PipeGeom {
     int32_t qpl;
     int32_t gram_off;             // producer LDS: offset (doubles) of the Gram reduction buffer
     int32_t sub_per_block;        // scan sub-windows per producer block (8 * rows_per_wave / w)
-    int32_t split_roles, pad1;    // producer block: waves 0..3 evaluate rows, waves 4..7 the Gram blocks behind them
+    int32_t split_roles;          // producer block: waves 0..3 evaluate rows, waves 4..7 the Gram blocks behind them
+    int32_t recompute_new;        // producers store no `new` rows; the scan block re-evaluates the accepted ones at the end of its tick
     uint64_t prod_lds, scan_lds;
 };
 
@@ -82,6 +83,7 @@ struct PipeArgs {
     double *dwin;                 // [R][2][kb][qpad]   d rows of the window
     double *gwin;                 // [R][2][kb][w]      Gram blocks: row = step in the window, column = step in ITS sub-window
     double *scal;                 // [R][2][kb][4]   a = Σ w d, e = Σ wI d, g = Σ w d² of every step's row
+    double *pcon;                 // [R][2][kb][PIPE_CON_DOUBLES]  the proposal's Contrib<M> (what its row evaluation needs)
     double *pval;                 // [R][2][kb][MAX_ACTIVE]
     int32_t *povf;                // [R][2][kb]
     int32_t *n_done;              // host-mapped: number of finished chains
@@ -103,11 +105,12 @@ __device__ __forceinline__ void store_snap(PipeSnap *p, const PipeSnap &s) {
 
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
 constexpr int PIPE_WAVES = PIPE_BLOCK / 64;
+constexpr int PIPE_CON_DOUBLES = 12;     // >= sizeof(Contrib<M>) / 8 of the models whose accepted rows the scan block re-evaluates
 constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;
 constexpr int PIPE_MAX_ROW_DOUBLES = 32;   // scan block: doubles per lane held in row registers (rows per wave and sub-window x q per lane)   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
-static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int split_req, PipeGeom *g) {
+static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int split_req, int recompute_req, int sub_req, PipeGeom *g) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
@@ -148,7 +151,7 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     for (int ws = 8; ws <= 8 * rpw && ws <= 64; ws += 8) {
         const int rps = ws / 8;
         if (rps == 5 || rps == 7 || rps * qpl > PIPE_MAX_ROW_DOUBLES) continue;   // the kernels instantiate 1, 2, 3, 4, 6, 8 rows per wave
-        if ((8 * rpw) % ws == 0 && sizeof(double) * (size_t)ws * qpad <= 96 * 1024) g->w = ws;
+        if ((8 * rpw) % ws == 0 && sizeof(double) * (size_t)ws * qpad <= 96 * 1024 && (sub_req == 0 || ws <= 8 * sub_req)) g->w = ws;
     }
     g->sub_per_block = 8 * rpw / g->w;
     g->rows_per_wave = rpw;
@@ -158,6 +161,7 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     // SIMD) and four Gram waves one sub-window behind them keep both pipes busy at once.  Rows with an integral keep
     // all eight waves on rows (their long dependent chains need two waves per SIMD).
     g->split_roles = (heavy_rows || !split_req) ? 0 : 1;
+    g->recompute_new = (heavy_rows || !recompute_req) ? 0 : 1;
     {
         const int tg = (g->w + 15) / 16, nt = tg * (tg + 1) / 2;
         size_t red = (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256;
@@ -171,6 +175,18 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
                 + sizeof(int32_t) * (4 * (size_t)g->kb + 1 + 1 + 64 + 4 + 8) + 64;
     if (g->scan_lds > 160 * 1024 || g->prod_lds > 160 * 1024) return 1;
     return 0;
+}
+
+// Models whose ACCEPTED rows the scan block evaluates again itself (a few hundred instructions per row, ~6 % of the
+// steps) instead of having every proposal's row written to HBM by the producers (4 KB per step): the ones without an
+// orientation / contour integral.  Same function, same inputs as RowEval -> the same bits.
+constexpr bool pipe_light_model(int m) {
+    return m == MCSAS_MODEL_SPHERE || m == MCSAS_MODEL_SPH_CS || m == MCSAS_MODEL_GAUSS_CHAIN || m == MCSAS_MODEL_LMA_SPHERE;
+}
+template <int M>
+__device__ __forceinline__ double pipe_point_intensity(const Contrib<M> &c, double q, double q3inv) {
+    if constexpr (M == MCSAS_MODEL_SPHERE) return c.fast ? c.intensity_fast(q, q3inv) : c.intensity(q, nullptr);
+    else return c.intensity(q, nullptr);
 }
 
 // one row of the window buffers as every kernel here holds it in registers: 16-byte loads, lane l and
@@ -446,6 +462,17 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     }
 
     if (a.pad0 & 16) return;                                  // diagnostic: no window rows
+    const bool keep_new = !(pipe_light_model(M) && pa.g.recompute_new);
+    auto pcon = glb(pa.pcon) + ((size_t)rep * 2 + (t & 1)) * Kb * PIPE_CON_DOUBLES;
+    auto put_contrib = [&](int k, const Contrib<M> &c) {      // lane 0: the record the scan block re-evaluates an accepted row from
+        if constexpr (pipe_light_model(M)) {
+            static_assert(sizeof(Contrib<M>) <= 8 * PIPE_CON_DOUBLES && sizeof(Contrib<M>) % 8 == 0, "PIPE_CON_DOUBLES");
+            double tmp[PIPE_CON_DOUBLES] = {};
+            __builtin_memcpy(tmp, &c, sizeof(Contrib<M>));
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(Contrib<M>) / 8); ++i) pcon[(size_t)k * PIPE_CON_DOUBLES + i] = tmp[i];
+        }
+    };
     if (pa.g.split_roles) {
         // ---- role split (rows without an integral): waves 0..3 evaluate the block's rows sub-window by sub-window,
         // waves 4..7 follow one sub-window behind with its Gram block; hand-offs through LDS counters, no barrier
@@ -506,7 +533,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {
                         const int iq = lane + WAVE * j;
-                        nrow[WAVE * j] = nwv[j];
+                        if (keep_new) nrow[WAVE * j] = nwv[j];
                         d[j] = nwv[j] - d[j];
                         dr[WAVE * j] = d[j];
                         const double wd = lw[iq] * d[j];
@@ -521,7 +548,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
                             if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
                         }
                     const int ov = __builtin_amdgcn_readlane(pov, bl);
-                    if (lane == 0) povf[k] = ov;
+                    if (lane == 0) { povf[k] = ov; if (!keep_new) put_contrib(k, cnew); }
                 }
                 if ((l % RW) == RW - 1) {
                     // my rows of this sub-window are written: count this wave in for the Gram waves
@@ -615,7 +642,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
 #pragma unroll
         for (int j = 0; j < QPL; ++j) {
             const int iq = lane + WAVE * j;
-            nrow[WAVE * j] = nwv[j];
+            if (keep_new) nrow[WAVE * j] = nwv[j];
             d[j] = nwv[j] - d[j];
             dr[WAVE * j] = d[j];
             const double wd = lw[iq] * d[j];
@@ -630,7 +657,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
                 if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
             }
         const int ov = __builtin_amdgcn_readlane(pov, bl);
-        if (lane == 0) povf[k] = ov;
+        if (lane == 0) { povf[k] = ov; if (!keep_new) put_contrib(k, cnew); }
         ri = (ri + 1 == N) ? 0 : ri + 1;
     }
     // ---- the sub-window's Gram block from the d rows the block has just written (workgroup-scope visibility:
@@ -667,7 +694,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
 
 // ------------------------------------------------------------------------------------ scanner
 // LDS: two Gram blocks, ft and w*ft, the window's scalars, h of the current sub-window, flags and slot tables
-template <int QPL, int RPS>                                    // RPS = rows per wave and sub-window (W / 8), compile time: see `request`
+template <int M, int QPL, int RPS>                             // RPS = rows per wave and sub-window (W / 8), compile time: see `request`
 __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds, int rep, int t, int stop_now) {
     static_assert(PIPE_GRAM_TILES_PER_ROUND * 256 == PIPE_BLOCK, "Gram reduction maps one thread to one tile element");
     const ChainArgs &a = pa.c;
@@ -962,6 +989,31 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #endif
         if (wave == 0 && lane == 0) lacc[Kb] = num_acc_win;
         PIPE_LDS_BARRIER();
+        if constexpr (pipe_light_model(M)) {
+            // ---- the rows of the accepted steps, evaluated again from their Contrib records and stored into the row
+            // slots their contributions now own (the producers kept none of the window's `new` rows): off the
+            // decision path, one q per thread, records staged through the (now idle) row buffer
+            const int nacc = lacc[Kb];
+            if (pa.g.recompute_new && nacc > 0) {
+                const auto pcon = glb((const double *)pa.pcon) + ((size_t)rep * 2 + buf) * Kb * PIPE_CON_DOUBLES;
+                double *lrec = rowbuf;
+                for (int i = tid; i < nacc * PIPE_CON_DOUBLES; i += T)
+                    lrec[i] = pcon[(size_t)lacc[i / PIPE_CON_DOUBLES] * PIPE_CON_DOUBLES + (i % PIPE_CON_DOUBLES)];
+                PIPE_LDS_BARRIER();
+#pragma unroll
+                for (int x = 0; x < QT; ++x) {
+                    const int i = tid + T * x;
+                    if (i < qpad) {
+                        const double qq = glb(a.q)[i], q3 = 1.0 / (qq * qq * qq);     // as the producers' tables
+                        for (int n = 0; n < nacc; ++n) {
+                            Contrib<M> c;
+                            __builtin_memcpy(&c, lrec + (size_t)n * PIPE_CON_DOUBLES, sizeof(Contrib<M>));
+                            cache[(size_t)lslot[lacc[n]] * qpad + i] = pipe_point_intensity<M>(c, qq, q3);
+                        }
+                    }
+                }
+            }
+        }
         {   // write the window's slot tables back and store the accepted proposals (mcsas.py:381), all waves
             const int nacc = lacc[Kb];
             if (nacc > 0) {
@@ -1088,7 +1140,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
         if (t >= 0) {
             // rows per wave and sub-window: uniform for the launch; the host only picks combinations instantiated here
             switch (pa.g.w >> 3) {
-#define PIPE_SCAN_CASE(r) case r: if constexpr (r * QPL <= PIPE_MAX_ROW_DOUBLES) pipe_scan_block<QPL, r>(pa, lds, b, t, stop_now); break;
+#define PIPE_SCAN_CASE(r) case r: if constexpr (r * QPL <= PIPE_MAX_ROW_DOUBLES) pipe_scan_block<M, QPL, r>(pa, lds, b, t, stop_now); break;
                 PIPE_SCAN_CASE(1) PIPE_SCAN_CASE(2) PIPE_SCAN_CASE(3) PIPE_SCAN_CASE(4) PIPE_SCAN_CASE(6) PIPE_SCAN_CASE(8)
 #undef PIPE_SCAN_CASE
                 default: break;

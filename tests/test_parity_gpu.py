@@ -723,16 +723,27 @@ def test_more_than_4096_q_points_is_refused_loudly():
     assert e.value.code == -1 and "4096" in str(e.value)
 
 
-def test_role_split_producer_blocks_replay_the_reference():
+def test_pipeline_tuning_variants_replay_the_reference():
     """The alternative producer layout of the pipeline (four row waves + four Gram waves per block with LDS
     hand-offs, tuning bit 16 of the diagnostic word) is kept for measurements: it replays the reference's
     512 q x 400 contribution chain like the default layout does.  (Its Gram blocks are summed over four q ranges
     instead of eight, so a free-running chain may take a different turn at a numerically tied step — replacing one
     negligible sphere by another moves chi² by less than its rounding error — which is why the comparison is with
     the reference, not with the default layout.)"""
-    g, m, spec, st, ost = traj_setup("g4_sphere_q512_fixed.npz")
-    st.exec_mode, st.debug_flags = engine.EXEC_PIPELINE, 1 << 16
-    res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st, replay=g["stream"][None, :])
-    assert res.num_iter[0] == int(g["res_num_iter"]) and res.num_moves[0] == int(g["res_num_moves"])
-    np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
-    np.testing.assert_allclose(res.chisq[0], float(g["res_conval"]), rtol=1e-7)
+    # bit 16: role split; bit 17: producers keep no `new` rows, the scan block re-evaluates the accepted ones; bits 12-15:
+    # scan sub-window capped at 16 / 8 steps; bits 8-11: 8 / 4 / 2 rows per producer wave
+    for flags in (1 << 16, 1 << 17, (1 << 16) | (1 << 17), 2 << 12, 1 << 12, 8 << 8, 4 << 8, (2 << 8) | (1 << 17)):
+        g, m, spec, st, ost = traj_setup("g4_sphere_q512_fixed.npz")
+        st.exec_mode, st.debug_flags = engine.EXEC_PIPELINE, flags
+        res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st, replay=g["stream"][None, :])
+        assert res.num_iter[0] == int(g["res_num_iter"]) and res.num_moves[0] == int(g["res_num_moves"]), flags
+        np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
+        np.testing.assert_allclose(res.chisq[0], float(g["res_conval"]), rtol=1e-7)
+    # the re-evaluation path of the other models without an integral, against their reference replays
+    for name in ("g4_sphcs_q40.npz", "g4_gausschain_q40.npz", "g4_lmasphere_q40.npz", "g7_sphere_q100_smeared.npz"):
+        g, m, spec, st, ost = traj_setup(name)
+        _, psm = traj_smearing(g)
+        st.exec_mode, st.debug_flags = engine.EXEC_PIPELINE, 1 << 17
+        res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st, replay=g["stream"][None, :], smear=psm)
+        assert res.num_moves[0] == int(g["res_num_moves"]), name
+        np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
