@@ -29,17 +29,29 @@ def bench_line(tag):
     raise SystemExit("no bench line in " + p)
 
 
-def counters(tag, group, kernel_rx):
+def counters(tag, group, kernel_rx, skip_init=False):
+    """Sums per counter over the dispatches of the named kernel.  skip_init (pipeline): the first tick dispatch
+    behind every pipe_reset_kernel dispatch evaluates the N initial rows of every chain — chain initialisation, not
+    MC steps — and is left out (its sum is returned separately)."""
     f = find(os.path.join(RAW, "%s_%s" % (tag, group)), "*counter_collection.csv")
     if not f:
-        return {}, 0
-    tot, disp = {}, set()
-    for r in csv.DictReader(open(f)):
+        return {}, 0, {}
+    rows = list(csv.DictReader(open(f)))
+    order = sorted(set((int(r["Dispatch_Id"]), r["Kernel_Name"]) for r in rows))
+    init_ids, after_reset = set(), False
+    for did, name in order:
+        if "pipe_reset_kernel" in name:
+            after_reset = True
+        elif after_reset and re.search(kernel_rx, name):
+            init_ids.add(did); after_reset = False
+    tot, init, disp = {}, {}, set()
+    for r in rows:
         if not re.search(kernel_rx, r["Kernel_Name"]):
             continue
-        tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        tgt = init if (skip_init and int(r["Dispatch_Id"]) in init_ids) else tot
+        tgt[r["Counter_Name"]] = tgt.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         disp.add(r["Dispatch_Id"])
-    return tot, len(disp)
+    return tot, len(disp), init
 
 
 def main():
@@ -79,7 +91,10 @@ def main():
                     bl = json.loads(l); break
             if bl is None:
                 continue
-            tot, nd = counters(tag, group, rx)
+            tot, nd, init = counters(tag, group, rx, skip_init=cfg is not None)
+            if group == "sq1" and init.get("SQ_INSTS_VALU"):
+                md += ["(chain initialisation, left out of the table: %.3e VALU wave-instructions = %.1f %% of the run's)"
+                       % (init["SQ_INSTS_VALU"], 100 * init["SQ_INSTS_VALU"] / (init["SQ_INSTS_VALU"] + tot.get("SQ_INSTS_VALU", 0))), ""]
             # MC steps executed in the counter run = (timed + warm-up launches) x steps per launch
             per_launch = bl["value"] * bl["timed_region_s"] / max(bl["launch_ms"]["n"], 1)
             n_launch = (bl["steps"] + bl["warmup"]) * bl["config"]["launches_per_step"]
@@ -104,8 +119,8 @@ def main():
         bl = [json.loads(l) for l in open(fb).read().splitlines() if l.startswith("{")][-1]
         per_launch = bl["value"] * bl["timed_region_s"] / max(bl["launch_ms"]["n"], 1)
         mc = per_launch * (bl["steps"] + bl["warmup"]) * bl["config"]["launches_per_step"]
-        f, nf = counters("c2", "fetch", r"pipe_tick_kernel")
-        w, nw = counters("c2", "write", r"pipe_tick_kernel")
+        f, nf, _ = counters("c2", "fetch", r"pipe_tick_kernel")
+        w, nw, _ = counters("c2", "write", r"pipe_tick_kernel")
         fbytes = 2.0 * f.get("FETCH_SIZE", 0) * 1024 / mc
         wbytes = w.get("WRITE_SIZE", 0) * 1024 / mc
         json.dump({"fetch_bytes_per_mc_step": fbytes, "write_bytes_per_mc_step": wbytes, "commit": commit},
