@@ -38,6 +38,24 @@ namespace mcsas {
 // SGPRs can hold, and spilled SGPRs come back one v_readlane at a time on the critical path.
 #define MCSAS_IN_VGPR(x) asm volatile("" : "+v"(x))
 
+// Producer row loop: the memory counter of gfx950 is in order over loads AND stores, so a wait for the `old` row of the
+// next step that comes behind this step's sixteen row stores drains them (a memory round trip per row).  The rows are
+// therefore waited for HERE, in front of the stores: everything outstanding at this point was issued before the row was
+// evaluated.  Routing the values through an empty asm pins the wait (and the stores behind it) to this place.
+#ifdef MCSAS_STAMPS
+#define PIPE_TL_WRITE(pa, t, i) do { if ((pa).timeline && (t) - 1 == (pa).timeline_tick && (threadIdx.x & 63) == 0) (pa).timeline[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define PIPE_TL_WRITE(pa, t, i) do {} while (0)
+#endif
+#ifdef MCSAS_TLX                         // the four marks show the producer's start-up instead of its phases
+#define PIPE_TLX_MARK(pa, t, i) PIPE_TL_WRITE(pa, t, i)
+#define PIPE_TL_MARK(pa, t, i) do {} while (0)
+#else
+#define PIPE_TLX_MARK(pa, t, i) do {} while (0)
+#define PIPE_TL_MARK(pa, t, i) PIPE_TL_WRITE(pa, t, i)
+#endif
+#define PIPE_PIN_ROW(arr) do { _Pragma("unroll") for (int j_ = 0; j_ < QPL; ++j_) asm volatile("" : "+v"(arr[j_])); } while (0)
+
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 
@@ -70,6 +88,8 @@ struct PipeGeom {
     int32_t sub_per_block;        // scan sub-windows per producer block (8 * rows_per_wave / w)
     int32_t split_roles;          // producer block: waves 0..3 evaluate rows, waves 4..7 the Gram blocks behind them
     int32_t recompute_new;        // producers store no `new` rows; the scan block re-evaluates the accepted ones at the end of its tick
+    int32_t gram_lds;             // producer: the sub-window's d rows are also kept in LDS and the Gram MFMAs read them from there
+    int32_t drow_off;             // producer LDS: offset (doubles) of those rows, row stride qpad + PIPE_DROW_PAD
     uint64_t prod_lds, scan_lds;
 };
 
@@ -88,6 +108,8 @@ struct PipeArgs {
     int32_t *povf;                // [R][2][kb]
     int32_t *n_done;              // host-mapped: number of finished chains
     int32_t tick, pad;            // unused: the tick travels as its own kernel argument
+    uint64_t *timeline;           // stamps build: [blocks][8 waves][2] wall clock (10 ns) at wave start / end of tick `timeline_tick`
+    int32_t timeline_tick, pad1;
 };
 
 // schedule records go through scalar global loads / stores (a struct copy out of an address-space-qualified
@@ -107,10 +129,11 @@ constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel
 constexpr int PIPE_WAVES = PIPE_BLOCK / 64;
 constexpr int PIPE_CON_DOUBLES = 12;     // >= sizeof(Contrib<M>) / 8 of the models whose accepted rows the scan block re-evaluates
 constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;
+constexpr int PIPE_DROW_PAD = 8;         // LDS d rows: stride qpad + 8 doubles, so that the 64 16-byte operands of one Gram load hit 64 different bank groups
 constexpr int PIPE_MAX_ROW_DOUBLES = 32;   // scan block: doubles per lane held in row registers (rows per wave and sub-window x q per lane)   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
-static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int split_req, int recompute_req, int sub_req, PipeGeom *g) {
+static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int split_req, int recompute_req, int sub_req, int gram_global_req, PipeGeom *g) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
@@ -167,6 +190,13 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         size_t red = (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256;
         if (g->split_roles) red = (size_t)g->sub_per_block * 4 * nt * 256;
         g->prod_lds = sizeof(double) * ((size_t)g->gram_off + 16 + red);    // 16 doubles: hand-off counters
+        // Rows without an integral: the Gram phase is a third of the producer's tick; with the sub-window's d rows parked
+        // in LDS on their way to HBM it is MFMA-bound instead of waiting for an L2 round trip per sub-window.
+        g->gram_lds = 0; g->drow_off = 0;
+        const size_t with_rows = g->prod_lds + sizeof(double) * (size_t)g->w * (qpad + PIPE_DROW_PAD);
+        if (!heavy_rows && !g->split_roles && !gram_global_req && with_rows <= 160 * 1024) {
+            g->gram_lds = 1; g->drow_off = g->gram_off + 16 + (int)red; g->prod_lds = with_rows;
+        }
     }
     g->scan_waves = PIPE_WAVES;
     // scan block LDS: the sub-window's d rows, two Gram blocks (double buffer), ft and w*ft, the window's scalars, h of
@@ -336,6 +366,110 @@ __device__ __forceinline__ void pipe_prod_gram(const MCSAS_GLOBAL double *drows,
 }
 
 
+// The same Gram block with the operands read from the LDS copy of the sub-window's d rows (row stride dstr).
+// PACK (W = 24, three 8-row groups g0 g1 g2): the six upper-triangular 8x8 blocks fit TWO 16x16 tiles instead of the
+// three of the 16-row grouping — tile 0 = rows [g0 g1] x columns [g1 g2] (blocks 01 02 11 12), tile 1 = rows and
+// columns [g0 g2] (blocks 00 22; its 02 is a duplicate and not stored): a third fewer MFMAs.
+template <int QPL, int T, bool PACK>
+__device__ __forceinline__ void pipe_gram_mfma_lds(const double *drows, int dstr, int nvalid, const double *lw, int gw,
+                                                   v4f64 (&acc)[PACK ? 2 : T * (T + 1) / 2]) {
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kk = lane >> 4;
+    constexpr int NT = PACK ? 2 : T * (T + 1) / 2;
+    constexpr int NL = PACK ? 3 : T;                          // row operands per lane and step-pair
+    constexpr int SLICE = 64 * QPL / PIPE_WAVES;
+    static_assert(SLICE >= 8, "too many waves for this q count");
+    const int qs = gw * SLICE + kk * 2;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0., 0., 0., 0.};
+    const double *rowp[NL];
+    bool rowok[NL];
+#pragma unroll
+    for (int gi = 0; gi < NL; ++gi) {
+        const int rr = PACK ? (gi == 0 ? m : gi == 1 ? 8 + m : (m < 8 ? m : m + 8)) : 16 * gi + m;
+        rowok[gi] = rr < nvalid;
+        rowp[gi] = drows + (size_t)(rowok[gi] ? rr : 0) * dstr + qs;
+    }
+#pragma unroll
+    for (int sp = 0; sp < SLICE / 8; ++sp) {
+        v2f64 av[NL], bv[NL];
+        const v2f64 wv = *reinterpret_cast<const v2f64 *>(lw + qs + 8 * sp);
+#pragma unroll
+        for (int gi = 0; gi < NL; ++gi) {
+            const v2f64 x = *reinterpret_cast<const v2f64 *>(rowp[gi] + 8 * sp);
+            av[gi] = rowok[gi] ? x : (v2f64){0., 0.};
+            bv[gi] = av[gi] * wv;
+        }
+        if constexpr (PACK) {
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0].x, bv[1].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2].x, bv[2].x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0].y, bv[1].y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2].y, bv[2].y, acc[1], 0, 0, 0);
+        } else {
+            int ti = 0;
+#pragma unroll
+            for (int gi = 0; gi < T; ++gi)
+#pragma unroll
+                for (int gj = gi; gj < T; ++gj) {
+                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].x, bv[gj].x, acc[ti], 0, 0, 0);
+                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].y, bv[gj].y, acc[ti], 0, 0, 0);
+                    ++ti;
+                }
+        }
+    }
+}
+
+// element idx of packed tile tsel -> (row, column) of the 24-step sub-window, or skipped
+__device__ __forceinline__ void pipe_gram_store_pack(int tsel, int idx, double sum, MCSAS_GLOBAL double *gout) {
+    const int i = 4 * (idx >> 6) + ((idx & 63) >> 4), j = idx & 15;
+    if (tsel == 0) gout[(size_t)i * 24 + 8 + j] = sum;
+    else if ((i < 8) == (j < 8)) gout[(size_t)(i < 8 ? i : i + 8) * 24 + (j < 8 ? j : j + 8)] = sum;
+}
+
+template <int QPL, int T, bool PACK>
+__device__ __forceinline__ void pipe_prod_gram_lds_t(const double *drows, int dstr, int W, int nvalid, const double *lw,
+                                                     double *gred, MCSAS_GLOBAL double *gout) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NT = PACK ? 2 : T * (T + 1) / 2;
+    v4f64 acc[NT];
+    pipe_gram_mfma_lds<QPL, T, PACK>(drows, dstr, nvalid, lw, wave, acc);
+    constexpr int TPR = PIPE_GRAM_TILES_PER_ROUND;
+#pragma unroll
+    for (int r0 = 0; r0 < NT; r0 += TPR) {
+#pragma unroll
+        for (int u = 0; u < TPR; ++u)
+            if (r0 + u < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gred[((size_t)(wave * TPR + u) * 4 + r) * 64 + lane] = acc[r0 + u < NT ? r0 + u : 0][r];
+            }
+        PIPE_LDS_BARRIER();
+        {
+            const int u = tid >> 8, idx = tid & 255;
+            const int tsel = r0 + u;
+            if (tsel < NT) {
+                double sum = 0.;
+#pragma unroll
+                for (int v = 0; v < PIPE_WAVES; ++v) sum += gred[(size_t)(v * TPR + u) * 256 + idx];
+                if constexpr (PACK) pipe_gram_store_pack(tsel, idx, sum, gout);
+                else pipe_gram_store<T>(tsel, idx, sum, W, gout);
+            }
+        }
+        if (r0 + TPR < NT) PIPE_LDS_BARRIER();
+    }
+}
+
+template <int QPL>
+__device__ __forceinline__ void pipe_prod_gram_lds(const double *drows, int dstr, int W, int nvalid, const double *lw,
+                                                   double *gred, MCSAS_GLOBAL double *gout) {
+    if (W == 24) { pipe_prod_gram_lds_t<QPL, 2, true>(drows, dstr, W, nvalid, lw, gred, gout); return; }
+    switch ((W + 15) >> 4) {                                   // uniform for the launch
+        case 1: pipe_prod_gram_lds_t<QPL, 1, false>(drows, dstr, W, nvalid, lw, gred, gout); break;
+        case 2: pipe_prod_gram_lds_t<QPL, 2, false>(drows, dstr, W, nvalid, lw, gred, gout); break;
+        case 3: pipe_prod_gram_lds_t<QPL, 3, false>(drows, dstr, W, nvalid, lw, gred, gout); break;
+        default: pipe_prod_gram_lds_t<QPL, 4, false>(drows, dstr, W, nvalid, lw, gred, gout); break;
+    }
+}
+
 // Waves 4..7 of a role-split producer block (gv = wave - 4): same tiles, the q range split four ways, and no
 // workgroup barrier — the row waves are busy with the next sub-window.  Each Gram wave parks its partial tiles in
 // LDS and counts itself in; when all four are in, every wave sums a quarter of the elements in wave order
@@ -391,6 +525,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int WPB = PIPE_BLOCK / 64;
     const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb;
+    const int64_t max_iter = a.max_iter;                      // a local copy: a field of the argument block read inside the row loop is a global load + full wait per row
     // the data tables do not depend on the chain's schedule record: both round trips run side by side
     constexpr int QTB = (QPL * 64 + PIPE_BLOCK - 1) / PIPE_BLOCK;
     double tq[QTB], tw[QTB], twI[QTB];
@@ -495,7 +630,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
                 for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
                     if (p < P) {
                         double u = 0.5;
-                        if (lane < nmine && sl < a.max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
+                        if (lane < nmine && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
                         prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
                     }
                 if (lane < nmine) {
@@ -505,36 +640,36 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
             }
             Contrib<M> prop;
             prop.prepare(a.model, prow);
-            double onext[QPL];
+            double ocur[QPL], onext[QPL];
             {
                 const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
 #pragma unroll
-                for (int j = 0; j < QPL; ++j) onext[j] = orow0[WAVE * j];
+                for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
             }
+            PIPE_PIN_ROW(ocur);                                   // (a pending load carried into the loop would be waited for at its head, every iteration)
             for (int l = 0; l < nmine; ++l) {
                 const int bl = __builtin_amdgcn_readfirstlane(l);
                 const int kl = (l / RW) * W + wave * RW + (l % RW), k = by * BR + kl;
                 const Contrib<M> cnew = prop.bcast(bl);
                 const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
                 double d[QPL], nwv[QPL];
-#pragma unroll
-                for (int j = 0; j < QPL; ++j) d[j] = onext[j];
                 {
                     const int bn = __builtin_amdgcn_readfirstlane(l + 1 < nmine ? l + 1 : l);
                     const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bn) * qpad + lane;
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) onext[j] = orow[WAVE * j];
                 }
-                if (sb0 + kl < a.max_iter) {                                          // uniform
+                if (sb0 + kl < max_iter) {                                          // uniform
                     const auto nrow = cache + (size_t)sslot * qpad + lane;
                     const auto dr = dwin + (size_t)k * qpad + lane;
                     RowEval<M, QPL>::run(cnew, qt, lane, nwv);
+                    PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
                     double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {
                         const int iq = lane + WAVE * j;
                         if (keep_new) nrow[WAVE * j] = nwv[j];
-                        d[j] = nwv[j] - d[j];
+                        d[j] = nwv[j] - ocur[j];
                         dr[WAVE * j] = d[j];
                         const double wd = lw[iq] * d[j];
                         s1 += wd; s2 += lwI[iq] * d[j]; s3 += wd * d[j];
@@ -549,7 +684,11 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
                         }
                     const int ov = __builtin_amdgcn_readlane(pov, bl);
                     if (lane == 0) { povf[k] = ov; if (!keep_new) put_contrib(k, cnew); }
+                } else {
+                    PIPE_PIN_ROW(onext);
                 }
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) ocur[j] = onext[j];
                 if ((l % RW) == RW - 1) {
                     // my rows of this sub-window are written: count this wave in for the Gram waves
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -563,7 +702,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
             bool ok = true;
             for (int ss = 0; ss < nsb && ok; ++ss) {
                 const int sub = by * nsb + ss;
-                const int64_t left = a.max_iter - (w * Kb + (int64_t)sub * W);
+                const int64_t left = max_iter - (w * Kb + (int64_t)sub * W);
                 const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
                 ok = pipe_spin_until(&handoff[0], 4 * (ss + 1));                      // the four row waves have stored sub-window ss
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -576,8 +715,127 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
         return;
     }
 
+    if (pa.g.gram_lds) {
+        // ---- sub-window by sub-window: every wave evaluates its W/8 rows of the sub-window (d also into the LDS row
+        // buffer), barrier, the eight waves take the Gram block from LDS, next sub-window.  Only the LDS traffic is
+        // waited for at the barriers: the rows' global stores drain behind the MFMAs.
+        MCSAS_STAMP_DECL(pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0, tg = 0, tb = 0);
+        MCSAS_STAMP(pp0);
+        const int W = pa.g.w, nsb = pa.g.sub_per_block, RW = W >> 3, BR = nsb * W;   // RW rows per wave and sub-window
+        const int buf = t & 1, dstr = qpad + PIPE_DROW_PAD;
+        const int64_t w = (int64_t)t - sn.t_init - 1;
+        const int64_t sb0 = w * Kb + (int64_t)by * BR;                                 // global step of the block's first row
+        auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
+        auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
+        auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
+        auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
+        double *dbuf = lds + pa.g.drow_off, *gred = lds + pa.g.gram_off + 16;
+        const int nmine = nsb * RW;                                                    // my rows (<= 8), lane l <-> my l-th row
+        const bool no_gram = a.pad0 & 64;                                              // diagnostic: no Gram blocks (uniform)
+        const int lrow = (lane / RW) * W + wave * RW + (lane % RW);                     // its offset in the block
+        double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+        int pov = 0, my_oslot = 0, my_sslot = 0;
+        {
+            const int64_t sl = sb0 + lrow;
+#pragma unroll
+            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+                if (p < P) {
+                    double u = 0.5;
+                    if (lane < nmine && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
+                    prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
+                }
+            if (lane < nmine) {
+                const int r = (int)((sb0 + lrow) % N);
+                my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + by * BR + lrow];
+            }
+        }
+        Contrib<M> prop;
+        prop.prepare(a.model, prow);
+        double ocur[QPL], onext[QPL];
+        {
+            const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
+#pragma unroll
+            for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
+        }
+        PIPE_PIN_ROW(ocur);                                       // (a pending load carried into the loop would be waited for at its head, every iteration)
+        for (int ss = 0; ss < nsb; ++ss) {
+            for (int jr = 0; jr < RW; ++jr) {
+                const int l = ss * RW + jr, bl = __builtin_amdgcn_readfirstlane(l);
+                const int kl = ss * W + wave * RW + jr, k = by * BR + kl;
+                const Contrib<M> cnew = prop.bcast(bl);
+                const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
+                double d[QPL], nwv[QPL];
+                {
+                    const int bn = __builtin_amdgcn_readfirstlane(l + 1 < nmine ? l + 1 : l);
+                    const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bn) * qpad + lane;
+#pragma unroll
+                    for (int j = 0; j < QPL; ++j) onext[j] = orow[WAVE * j];
+                }
+                if (sb0 + kl < max_iter) {                                            // uniform in the wave; rows behind max_iter are masked in the Gram block
+                    const auto nrow = cache + (size_t)sslot * qpad + lane;
+                    const auto dr = dwin + (size_t)k * qpad + lane;
+                    double *dl = dbuf + (size_t)(wave * RW + jr) * dstr + lane;
+                    RowEval<M, QPL>::run(cnew, qt, lane, nwv);
+                    PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
+                    double s1 = 0., s2 = 0., s3 = 0.;
+#pragma unroll
+                    for (int j = 0; j < QPL; ++j) {
+                        const int iq = lane + WAVE * j;
+                        if (keep_new) nrow[WAVE * j] = nwv[j];
+                        d[j] = nwv[j] - ocur[j];
+                        dr[WAVE * j] = d[j];
+                        dl[WAVE * j] = d[j];
+                        const double wd = lw[iq] * d[j];
+                        s1 += wd; s2 += lwI[iq] * d[j]; s3 += wd * d[j];
+                    }
+                    wave_sum3(s1, s2, s3);
+                    if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
+#pragma unroll
+                    for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+                        if (p < P) {
+                            const double v = readlane_f64(prow[p], bl);
+                            if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
+                        }
+                    const int ov = __builtin_amdgcn_readlane(pov, bl);
+                    if (lane == 0) { povf[k] = ov; if (!keep_new) put_contrib(k, cnew); }
+                } else {
+                    PIPE_PIN_ROW(onext);
+                }
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) ocur[j] = onext[j];
+            }
+            MCSAS_STAMP(pp1);
+            PIPE_TL_MARK(pa, t, 2 * (ss & 1));
+            if (!no_gram) PIPE_LDS_BARRIER();                     // the sub-window's rows are in LDS
+            MCSAS_STAMP(pp2);
+            const int sub = by * nsb + ss;
+            const int64_t left = max_iter - (w * Kb + (int64_t)sub * W);
+            const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
+            if (nvalid > 1 && !no_gram)                           // uniform in the block
+                pipe_prod_gram_lds<QPL>(dbuf, dstr, W, nvalid, lw, gred, glb(pa.gwin) + (((size_t)rep * 2 + buf) * Kb + (size_t)sub * W) * W);
+            // (the next sub-window's rows overwrite dbuf only behind the reduction's first barrier, which every wave
+            // passes after its last operand read; gred is written again behind the next rows -> Gram barrier)
+            MCSAS_STAMP(pp3);
+            PIPE_TL_MARK(pa, t, 2 * (ss & 1) + 1);
+#ifdef MCSAS_STAMPS
+            tg += (pp3 - pp2); tb += (pp2 - pp1);
+#endif
+        }
+#ifdef MCSAS_STAMPS
+        if (by == 0 && tid == 0) {
+            PipeChain &chs = pa.chains[rep];
+            atomicAdd((unsigned long long *)&chs.dbg[8], (unsigned long long)(pp3 - pp0 - tg - tb));
+            atomicAdd((unsigned long long *)&chs.dbg[9], (unsigned long long)tb);
+            atomicAdd((unsigned long long *)&chs.dbg[10], (unsigned long long)tg);
+            atomicAdd((unsigned long long *)&chs.dbg[11], 1ull);
+        }
+#endif
+        return;
+    }
+
     MCSAS_STAMP_DECL(pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0);
     MCSAS_STAMP(pp0);
+    PIPE_TLX_MARK(pa, t, 0);
     // ---- window w of the attempt: this wave's rows k = gw*rpw .. +rpw-1, one proposal per lane
     const int64_t w = (int64_t)t - sn.t_init - 1;
     const int rpw = pa.g.rows_per_wave, buf = t & 1;
@@ -591,12 +849,13 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
         for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
             if (p < P) {
                 double u = 0.5;
-                if (lane < rpw && sl < a.max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
+                if (lane < rpw && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
                 prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
             }
     }
     Contrib<M> prop;
     prop.prepare(a.model, prow);
+    PIPE_TLX_MARK(pa, t, 1);
     auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
     auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
     auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
@@ -611,23 +870,24 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     }
     // the `old` row of step i + 1 is requested before the row of step i is evaluated: under a full chip an Infinity
     // Cache / HBM round trip is longer than one sphere row evaluation, one row of lookahead hides it
-    double onext[QPL];
+    double ocur[QPL], onext[QPL];
     {
         const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
+        PIPE_TLX_MARK(pa, t, 2);
 #pragma unroll
-        for (int j = 0; j < QPL; ++j) onext[j] = orow0[WAVE * j];
+        for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
     }
+    PIPE_PIN_ROW(ocur);                                           // (a pending load carried into the loop would be waited for at its head, every iteration)
+    PIPE_TLX_MARK(pa, t, 3);
     for (int i = 0; i < rpw; ++i) {
         const int k = k0 + i;
-        if (s0 + i >= a.max_iter) break;
+        if (s0 + i >= max_iter) break;
         const int bl = __builtin_amdgcn_readfirstlane(i);
         const Contrib<M> cnew = prop.bcast(bl);
         const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
         const auto nrow = cache + (size_t)sslot * qpad + lane;
         const auto dr = dwin + (size_t)k * qpad + lane;
         double d[QPL], nwv[QPL];
-#pragma unroll
-        for (int j = 0; j < QPL; ++j) d[j] = onext[j];
         {
             const int bn = __builtin_amdgcn_readfirstlane(i + 1 < rpw ? i + 1 : i);
             const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bn) * qpad + lane;
@@ -635,6 +895,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
             for (int j = 0; j < QPL; ++j) onext[j] = orow[WAVE * j];
         }
         RowEval<M, QPL>::run(cnew, qt, lane, nwv);
+        PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
         // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  (Taking the
         // sums in the scan block's pass over the row instead was measured: its single h pass is the serial part of a
         // tick, 5x the dot-product work there cost 8 us per tick, here it is spread over every CU.)
@@ -643,7 +904,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
         for (int j = 0; j < QPL; ++j) {
             const int iq = lane + WAVE * j;
             if (keep_new) nrow[WAVE * j] = nwv[j];
-            d[j] = nwv[j] - d[j];
+            d[j] = nwv[j] - ocur[j];
             dr[WAVE * j] = d[j];
             const double wd = lw[iq] * d[j];
             s1 += wd; s2 += lwI[iq] * d[j]; s3 += wd * d[j];
@@ -658,21 +919,25 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
             }
         const int ov = __builtin_amdgcn_readlane(pov, bl);
         if (lane == 0) { povf[k] = ov; if (!keep_new) put_contrib(k, cnew); }
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) ocur[j] = onext[j];
         ri = (ri + 1 == N) ? 0 : ri + 1;
     }
     // ---- the sub-window's Gram block from the d rows the block has just written (workgroup-scope visibility:
     // the barrier's fence; same CU, same L1)
     if (a.pad0 & 64) return;                                  // diagnostic: no Gram blocks
     MCSAS_STAMP(pp1);
+    PIPE_TL_MARK(pa, t, 0);
     __syncthreads();
     MCSAS_STAMP(pp2);
+    PIPE_TL_MARK(pa, t, 1);
     {
         // (one pass over both sub-windows with six accumulators and a single run of reduction rounds was measured:
         // no faster than one call per sub-window)
         const int W = pa.g.w, nsb = pa.g.sub_per_block;       // the block's rows are nsb scan sub-windows of W steps
         for (int ss = 0; ss < nsb; ++ss) {
             const int sub = by * nsb + ss;                    // sub-window index within the window
-            const int64_t left = a.max_iter - (w * Kb + (int64_t)sub * W);
+            const int64_t left = max_iter - (w * Kb + (int64_t)sub * W);
             const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
             if (nvalid > 1)
                 pipe_prod_gram<QPL>(dwin + (size_t)sub * W * qpad, qpad, W, nvalid, lw, lds + pa.g.gram_off + 16,
@@ -680,6 +945,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
             if (ss + 1 < nsb) PIPE_LDS_BARRIER();             // the reduction buffer is reused
         }
     }
+    PIPE_TL_MARK(pa, t, 2);
 #ifdef MCSAS_STAMPS
     MCSAS_STAMP(pp3);
     if (by == 0 && tid == 0) {                                // wave 0 of the chain's first producer block
@@ -1136,6 +1402,17 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
     extern __shared__ double lds[];
     const PipeArgs &pa = *pap;
     const int R = pa.c.n_reps, b = blockIdx.x, t = tick;
+#ifdef MCSAS_STAMPS
+    struct Timeline {                                          // one record per wave, written when the wave leaves the kernel
+        uint64_t *p, t0; uint32_t hw;
+        __device__ Timeline(const PipeArgs &pa, int tick) {
+            p = (pa.timeline && tick == pa.timeline_tick && (threadIdx.x & 63) == 0) ? pa.timeline + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 : nullptr;
+            t0 = wall_clock64();
+            hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        }
+        __device__ ~Timeline() { if (p) { p[0] = t0; p[1] = wall_clock64(); p[2] = hw; p[3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); } }   // XCC_ID
+    } timeline_record(pa, tick);
+#endif
     if (b < R) {
         if (t >= 0) {
             // rows per wave and sub-window: uniform for the launch; the host only picks combinations instantiated here

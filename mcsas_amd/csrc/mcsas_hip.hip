@@ -350,6 +350,7 @@ struct mcsas_plan {
     PipeChain *d_chains = nullptr;
     double *d_ft = nullptr, *d_wft = nullptr, *d_dwin = nullptr, *d_gwin = nullptr, *d_scal = nullptr, *d_pcon = nullptr, *d_pval = nullptr;
     int32_t *d_slot_of = nullptr, *d_stage = nullptr, *d_povf = nullptr;
+    uint64_t *d_timeline = nullptr;
     int32_t *h_done = nullptr;          // pinned + mapped: scan kernels count finished chains into it
     PipeArgs *d_pipeargs = nullptr;     // the argument block the tick kernels read (device copy)
     hipStream_t sP = nullptr, sS = nullptr;
@@ -398,7 +399,7 @@ extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     if (pl->h_stop) hipHostFree(pl->h_stop);
     if (pl->h_done) hipHostFree(pl->h_done);
     hipFree(pl->d_pipeargs); hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_gwin); hipFree(pl->d_scal); hipFree(pl->d_pcon);
-    hipFree(pl->d_pval); hipFree(pl->d_slot_of); hipFree(pl->d_stage); hipFree(pl->d_povf);
+    hipFree(pl->d_timeline); hipFree(pl->d_pval); hipFree(pl->d_slot_of); hipFree(pl->d_stage); hipFree(pl->d_povf);
     for (int i = 0; i < mcsas_plan::RING; ++i) {
         if (pl->evP[i]) hipEventDestroy(pl->evP[i]);
         if (pl->evS[i]) hipEventDestroy(pl->evS[i]);
@@ -461,6 +462,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     const int rpw_req = (p->reserved0 >> 8) & 15;          // tuning / diagnostics: rows per producer wave of the pipeline, 0 = automatic
     const int split_req = (p->reserved0 >> 16) & 1;        // tuning: 1 = role-split producer blocks (row waves + Gram waves)
     const int recompute_req = (p->reserved0 >> 17) & 1;    // tuning: 1 = producers store no `new` rows, the scan block re-evaluates the accepted ones (measured: no gain)
+    const int gram_global_req = (p->reserved0 >> 18) & 1;  // tuning: 1 = Gram operands from the d rows in HBM/L2 (no LDS copy of the sub-window)
     const int sub_req = (p->reserved0 >> 12) & 15;         // tuning: cap on the scan sub-window, in units of 8 steps (0 = automatic)
 #define TABD(waves_per_block) (tab_shared + (waves_per_block) * tab_row)
     // execution mode (results do not depend on it)
@@ -475,7 +477,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             // one workgroup per chain up to ~400, one wavefront per chain beyond; rows that cost an integral
             // each keep the workgroup's seven producer waves per chain until the chains alone fill the SIMDs
             if (p->n_reps >= (heavy_rows ? 1024 : 448)) mode = MCSAS_EXEC_WAVE;
-            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, split_req, recompute_req, sub_req, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
+            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, split_req, recompute_req, sub_req, gram_global_req, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
             else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
             else mode = MCSAS_EXEC_WAVE;
         }
@@ -522,7 +524,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: needs 2*window <= n_contrib and the window in LDS (nq=%d, n_contrib=%d, waves=%d)", p->nq, (int)N, waves); }
         cache_rows = (int)N + 2 * pl->wg.window;
     } else if (mode == MCSAS_EXEC_PIPELINE) {
-        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, split_req, recompute_req, sub_req, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
+        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, split_req, recompute_req, sub_req, gram_global_req, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
         cache_rows = (int)N + 2 * pl->pipe.g.kb;
     }
     size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
@@ -595,6 +597,15 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         pa.chains = pl->d_chains; pa.ft = pl->d_ft; pa.wft = pl->d_wft; pa.slot_of = pl->d_slot_of;
         pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.gwin = pl->d_gwin; pa.scal = pl->d_scal; pa.pcon = pl->d_pcon; pa.pval = pl->d_pval;
         pa.povf = pl->d_povf; pa.n_done = d_done; pa.tick = 0;
+        pa.timeline = nullptr; pa.timeline_tick = -100;
+#ifdef MCSAS_STAMPS
+        if (const char *e = getenv("MCSAS_TIMELINE_TICK")) {
+            pa.timeline_tick = atoi(e);
+            PCHK(hipMalloc(&pl->d_timeline, sizeof(uint64_t) * 8 * 8 * (R + R * pa.g.prod_blocks_y)));
+            PCHK(hipMemset(pl->d_timeline, 0, sizeof(uint64_t) * 8 * 8 * (R + R * pa.g.prod_blocks_y)));
+            pa.timeline = pl->d_timeline;
+        }
+#endif
         pl->lds_bytes = std::max(pa.g.prod_lds, pa.g.scan_lds);
     }
     if (pl->lds_bytes > 160 * 1024) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "LDS need %zu B > 160 KiB", pl->lds_bytes); }
@@ -727,6 +738,21 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
             fprintf(stderr, "[mcsas stamps] rep %zu (wave 0 cycles):", r);
             for (int i = 0; i < 20; ++i) fprintf(stderr, " %s=%lld", names[i], (long long)ho[r].dbg[i]);
             fprintf(stderr, "\n");
+        }
+        if (pl->d_timeline) {
+            const size_t nb = R + R * pl->pipe.g.prod_blocks_y;
+            std::vector<uint64_t> tl(nb * 8 * 8);
+            HIPCHK(hipMemcpy(tl.data(), pl->d_timeline, tl.size() * 8, hipMemcpyDeviceToHost));
+            uint64_t t0 = ~0ull;
+            for (size_t i = 0; i < nb * 8; ++i) if (tl[i * 8] && tl[i * 8] < t0) t0 = tl[i * 8];
+            fprintf(stderr, "[mcsas timeline] tick %d: block wave start_us end_us hw_id xcc\n", pl->pipe.timeline_tick);
+            for (size_t i = 0; i < nb * 8; ++i)
+                if (tl[i * 8]) {
+                    fprintf(stderr, "[mcsas timeline] %zu %zu %.2f %.2f %llx %llu", i / 8, i % 8, (tl[i * 8] - t0) * 0.01, (tl[i * 8 + 1] - t0) * 0.01,
+                            (unsigned long long)tl[i * 8 + 2], (unsigned long long)tl[i * 8 + 3]);
+                    for (int m = 4; m < 8; ++m) fprintf(stderr, " %.2f", tl[i * 8 + m] ? (tl[i * 8 + m] - t0) * 0.01 : 0.0);
+                    fprintf(stderr, "\n");
+                }
         }
         fprintf(stderr, "[mcsas stamps] per rep: in-block us / gap us:");
         for (size_t r = 0; r < R; ++r) fprintf(stderr, " %.0f/%.0f", ho[r].dbg[18] * 0.01, ho[r].dbg[16] * 0.01);
