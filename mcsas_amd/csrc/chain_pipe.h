@@ -86,8 +86,8 @@ struct PipeGeom {
     int32_t qpl;
     int32_t gram_off;             // producer LDS: offset (doubles) of the Gram reduction buffer
     int32_t sub_per_block;        // scan sub-windows per producer block (8 * rows_per_wave / w)
-    int32_t split_roles;          // producer block: waves 0..3 evaluate rows, waves 4..7 the Gram blocks behind them
-    int32_t recompute_new;        // producers store no `new` rows; the scan block re-evaluates the accepted ones at the end of its tick
+    int32_t lazy_rows;            // no `new` rows are stored: an accepted step marks its contribution's cached row stale and the producer that
+                                  // next needs it as `old` evaluates it again from the parameter set (rows without an integral only)
     int32_t gram_lds;             // producer: the sub-window's d rows are also kept in LDS and the Gram MFMAs read them from there
     int32_t drow_off;             // producer LDS: offset (doubles) of those rows, row stride qpad + PIPE_DROW_PAD
     uint64_t prod_lds, scan_lds;
@@ -103,7 +103,7 @@ struct PipeArgs {
     double *dwin;                 // [R][2][kb][qpad]   d rows of the window
     double *gwin;                 // [R][2][kb][w]      Gram blocks: row = step in the window, column = step in ITS sub-window
     double *scal;                 // [R][2][kb][4]   a = Σ w d, e = Σ wI d, g = Σ w d² of every step's row
-    double *pcon;                 // [R][2][kb][PIPE_CON_DOUBLES]  the proposal's Contrib<M> (what its row evaluation needs)
+    int32_t *row_valid;           // [R][N]  lazy_rows: 1 = the contribution's cached row is current
     double *pval;                 // [R][2][kb][MAX_ACTIVE]
     int32_t *povf;                // [R][2][kb]
     int32_t *n_done;              // host-mapped: number of finished chains
@@ -127,13 +127,12 @@ __device__ __forceinline__ void store_snap(PipeSnap *p, const PipeSnap &s) {
 
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
 constexpr int PIPE_WAVES = PIPE_BLOCK / 64;
-constexpr int PIPE_CON_DOUBLES = 12;     // >= sizeof(Contrib<M>) / 8 of the models whose accepted rows the scan block re-evaluates
 constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;
 constexpr int PIPE_DROW_PAD = 8;         // LDS d rows: stride qpad + 8 doubles, so that the 64 16-byte operands of one Gram load hit 64 different bank groups
 constexpr int PIPE_MAX_ROW_DOUBLES = 32;   // scan block: doubles per lane held in row registers (rows per wave and sub-window x q per lane)   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
-static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int split_req, int recompute_req, int sub_req, int gram_global_req, PipeGeom *g) {
+static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int sub_req, int gram_global_req, int eager_req, PipeGeom *g) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
@@ -180,23 +179,20 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
     g->gram_off = 4 * qpad + tab_doubles;
-    // Rows without an integral are pure fp64 vector work, the Gram blocks pure MFMA work: four row waves (one per
-    // SIMD) and four Gram waves one sub-window behind them keep both pipes busy at once.  Rows with an integral keep
-    // all eight waves on rows (their long dependent chains need two waves per SIMD).
-    g->split_roles = (heavy_rows || !split_req) ? 0 : 1;
-    g->recompute_new = (heavy_rows || !recompute_req) ? 0 : 1;
     {
         const int tg = (g->w + 15) / 16, nt = tg * (tg + 1) / 2;
-        size_t red = (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256;
-        if (g->split_roles) red = (size_t)g->sub_per_block * 4 * nt * 256;
+        const size_t red = (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256;
+        (void)nt;
         g->prod_lds = sizeof(double) * ((size_t)g->gram_off + 16 + red);    // 16 doubles: hand-off counters
         // Rows without an integral: the Gram phase is a third of the producer's tick; with the sub-window's d rows parked
         // in LDS on their way to HBM it is MFMA-bound instead of waiting for an L2 round trip per sub-window.
         g->gram_lds = 0; g->drow_off = 0;
         const size_t with_rows = g->prod_lds + sizeof(double) * (size_t)g->w * (qpad + PIPE_DROW_PAD);
-        if (!heavy_rows && !g->split_roles && !gram_global_req && with_rows <= 160 * 1024) {
+        if (!heavy_rows && !gram_global_req && with_rows <= 160 * 1024) {
             g->gram_lds = 1; g->drow_off = g->gram_off + 16 + (int)red; g->prod_lds = with_rows;
         }
+        // ... and no `new` rows go to HBM either (4 KB per step at Q = 512, a fifth of the tick's memory traffic): see lazy_rows
+        g->lazy_rows = (g->gram_lds && !eager_req) ? 1 : 0;
     }
     g->scan_waves = PIPE_WAVES;
     // scan block LDS: the sub-window's d rows, two Gram blocks (double buffer), ft and w*ft, the window's scalars, h of
@@ -207,16 +203,17 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     return 0;
 }
 
-// Models whose ACCEPTED rows the scan block evaluates again itself (a few hundred instructions per row, ~6 % of the
-// steps) instead of having every proposal's row written to HBM by the producers (4 KB per step): the ones without an
-// orientation / contour integral.  Same function, same inputs as RowEval -> the same bits.
+// Models whose row costs a few hundred instructions (no orientation / contour integral): their producers store no `new`
+// rows (4 KB per step) — a contribution's cached row goes stale when its proposal is accepted and is evaluated again,
+// one q per thread, by the producer block that needs it as `old` N steps later (PipeGeom::lazy_rows).
+// Same function, same inputs as RowEval -> the same bits.
 constexpr bool pipe_light_model(int m) {
     return m == MCSAS_MODEL_SPHERE || m == MCSAS_MODEL_SPH_CS || m == MCSAS_MODEL_GAUSS_CHAIN || m == MCSAS_MODEL_LMA_SPHERE;
 }
 template <int M>
-__device__ __forceinline__ double pipe_point_intensity(const Contrib<M> &c, double q, double q3inv) {
-    if constexpr (M == MCSAS_MODEL_SPHERE) return c.fast ? c.intensity_fast(q, q3inv) : c.intensity(q, nullptr);
-    else return c.intensity(q, nullptr);
+__device__ __forceinline__ double pipe_point_intensity(const Contrib<M> &c, double q, double q3inv, const double *tab) {
+    if constexpr (M == MCSAS_MODEL_SPHERE) return c.fast ? c.intensity_fast(q, q3inv) : c.intensity(q, tab);
+    else return c.intensity(q, tab);
 }
 
 // one row of the window buffers as every kernel here holds it in registers: 16-byte loads, lane l and
@@ -470,55 +467,6 @@ __device__ __forceinline__ void pipe_prod_gram_lds(const double *drows, int dstr
     }
 }
 
-// Waves 4..7 of a role-split producer block (gv = wave - 4): same tiles, the q range split four ways, and no
-// workgroup barrier — the row waves are busy with the next sub-window.  Each Gram wave parks its partial tiles in
-// LDS and counts itself in; when all four are in, every wave sums a quarter of the elements in wave order
-// (deterministic) and stores them.  Spins are bounded: a hand-off that never comes sets *timeout instead of hanging.
-constexpr int PIPE_SPIN_LIMIT = 1 << 22;
-__device__ __forceinline__ bool pipe_spin_until(int32_t *word, int target) {
-    for (int n = 0; n < PIPE_SPIN_LIMIT; ++n) {
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-}
-template <int QPL, int T>
-__device__ __forceinline__ bool pipe_gram_flag_t(const MCSAS_GLOBAL double *drows, int qpad, int W, int nvalid, const double *lw,
-                                                 double *gred, int32_t *arrived, MCSAS_GLOBAL double *gout, int gv) {
-    const int lane = threadIdx.x & 63;
-    constexpr int NT = T * (T + 1) / 2;
-    v4f64 acc[NT];
-    pipe_gram_mfma<QPL, T, 4>(drows, qpad, nvalid, lw, gv, acc);
-#pragma unroll
-    for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gred[((size_t)(gv * NT + ti) * 4 + r) * 64 + lane] = acc[ti][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) atomicAdd(arrived, 1);
-    if (!pipe_spin_until(arrived, 4)) return false;
-    asm volatile("" ::: "memory");
-    // NT * 256 elements, a quarter per wave: element e = gv * (NT * 64) + n * 64 + lane
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int e = gv * (NT * 64) + n * 64 + lane, tsel = e >> 8, idx = e & 255;
-        double sum = 0.;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) sum += gred[(size_t)(v * NT + tsel) * 256 + idx];
-        pipe_gram_store<T>(tsel, idx, sum, W, gout);
-    }
-    return true;
-}
-template <int QPL>
-__device__ __forceinline__ bool pipe_gram_flag(const MCSAS_GLOBAL double *drows, int qpad, int W, int nvalid, const double *lw,
-                                               double *gred, int32_t *arrived, MCSAS_GLOBAL double *gout, int gv) {
-    switch ((W + 15) >> 4) {                                   // uniform for the launch
-        case 1: return pipe_gram_flag_t<QPL, 1>(drows, qpad, W, nvalid, lw, gred, arrived, gout, gv);
-        case 2: return pipe_gram_flag_t<QPL, 2>(drows, qpad, W, nvalid, lw, gred, arrived, gout, gv);
-        case 3: return pipe_gram_flag_t<QPL, 3>(drows, qpad, W, nvalid, lw, gred, arrived, gout, gv);
-        default: return pipe_gram_flag_t<QPL, 4>(drows, qpad, W, nvalid, lw, gred, arrived, gout, gv);
-    }
-}
-
 template <int M, int QPL>
 __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds, int rep, int by, int gy, int t) {
     const ChainArgs &a = pa.c;
@@ -544,8 +492,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
         if (i < qpad) { lq[i] = tq[x]; lw[i] = tw[x]; lwI[i] = twI[x]; lq3[i] = 1.0 / (tq[x] * tq[x] * tq[x]); }
     }
     Contrib<M>::fill_table(a.model, tab, tid, PIPE_BLOCK);
-    int32_t *handoff = reinterpret_cast<int32_t *>(lds + pa.g.gram_off);   // [0] row waves done per sub-window, [1 + ss] Gram waves in
-    if (tid < 32) handoff[tid] = 0;
+    if (tid == 0) *reinterpret_cast<int32_t *>(lds + pa.g.gram_off + 16) = 0;   // lazy rows: the block's stale-row count
     __syncthreads();
     const QTables qt = make_qtables<M>(a.model, lq, lq3, tab);
     auto rset = glb(a.rset) + (size_t)rep * N * P;
@@ -554,11 +501,12 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
                          (uint32_t)(a.rep_offset + rep)};
     auto slot_of = glb(pa.slot_of) + (size_t)rep * N;
     auto stage = glb(pa.stage_slot) + (size_t)rep * 2 * Kb;
+    auto row_valid = glb(pa.row_valid) + (size_t)rep * N;
     const int gw = by * WPB + wave, nw = gy * WPB;          // this wave's index among the chain's producer waves
 
     if (t == sn.t_init) {
         // ---- initial parameter set of the attempt (mcsas.py:310-319): rows n = gw*64 + lane + 64*nw*i
-        for (int i = tid + by * PIPE_BLOCK; i < N; i += PIPE_BLOCK * gy) slot_of[i] = i;
+        for (int i = tid + by * PIPE_BLOCK; i < N; i += PIPE_BLOCK * gy) { slot_of[i] = i; row_valid[i] = 1; }
         for (int i = tid + by * PIPE_BLOCK; i < 2 * Kb; i += PIPE_BLOCK * gy) stage[i] = N + i;
         int ovf = 0;
         // contribution n = lane*nw + gw + 64*nw*i: every producer wave of the chain owns ~N/nw rows
@@ -597,124 +545,6 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
     }
 
     if (a.pad0 & 16) return;                                  // diagnostic: no window rows
-    const bool keep_new = !(pipe_light_model(M) && pa.g.recompute_new);
-    auto pcon = glb(pa.pcon) + ((size_t)rep * 2 + (t & 1)) * Kb * PIPE_CON_DOUBLES;
-    auto put_contrib = [&](int k, const Contrib<M> &c) {      // lane 0: the record the scan block re-evaluates an accepted row from
-        if constexpr (pipe_light_model(M)) {
-            static_assert(sizeof(Contrib<M>) <= 8 * PIPE_CON_DOUBLES && sizeof(Contrib<M>) % 8 == 0, "PIPE_CON_DOUBLES");
-            double tmp[PIPE_CON_DOUBLES] = {};
-            __builtin_memcpy(tmp, &c, sizeof(Contrib<M>));
-#pragma unroll
-            for (int i = 0; i < (int)(sizeof(Contrib<M>) / 8); ++i) pcon[(size_t)k * PIPE_CON_DOUBLES + i] = tmp[i];
-        }
-    };
-    if (pa.g.split_roles) {
-        // ---- role split (rows without an integral): waves 0..3 evaluate the block's rows sub-window by sub-window,
-        // waves 4..7 follow one sub-window behind with its Gram block; hand-offs through LDS counters, no barrier
-        const int W = pa.g.w, nsb = pa.g.sub_per_block, RW = W >> 2, BR = nsb * W;     // RW rows per row wave and sub-window
-        const int buf = t & 1;
-        const int64_t w = (int64_t)t - sn.t_init - 1;
-        const int64_t sb0 = w * Kb + (int64_t)by * BR;                               // global step of the block's first row
-        auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
-        if (wave < 4) {
-            auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
-            auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
-            auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
-            const int nmine = nsb * RW;                                              // my rows (<= 16), lane l <-> my l-th row
-            const int lrow = (lane / RW) * W + wave * RW + (lane % RW);               // its offset in the block
-            double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
-            int pov = 0, my_oslot = 0, my_sslot = 0;
-            {
-                const int64_t sl = sb0 + lrow;
-#pragma unroll
-                for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
-                    if (p < P) {
-                        double u = 0.5;
-                        if (lane < nmine && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
-                        prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
-                    }
-                if (lane < nmine) {
-                    const int r = (int)((sb0 + lrow) % N);
-                    my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + by * BR + lrow];
-                }
-            }
-            Contrib<M> prop;
-            prop.prepare(a.model, prow);
-            double ocur[QPL], onext[QPL];
-            {
-                const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
-#pragma unroll
-                for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
-            }
-            PIPE_PIN_ROW(ocur);                                   // (a pending load carried into the loop would be waited for at its head, every iteration)
-            for (int l = 0; l < nmine; ++l) {
-                const int bl = __builtin_amdgcn_readfirstlane(l);
-                const int kl = (l / RW) * W + wave * RW + (l % RW), k = by * BR + kl;
-                const Contrib<M> cnew = prop.bcast(bl);
-                const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
-                double d[QPL], nwv[QPL];
-                {
-                    const int bn = __builtin_amdgcn_readfirstlane(l + 1 < nmine ? l + 1 : l);
-                    const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bn) * qpad + lane;
-#pragma unroll
-                    for (int j = 0; j < QPL; ++j) onext[j] = orow[WAVE * j];
-                }
-                if (sb0 + kl < max_iter) {                                          // uniform
-                    const auto nrow = cache + (size_t)sslot * qpad + lane;
-                    const auto dr = dwin + (size_t)k * qpad + lane;
-                    RowEval<M, QPL>::run(cnew, qt, lane, nwv);
-                    PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
-                    double s1 = 0., s2 = 0., s3 = 0.;
-#pragma unroll
-                    for (int j = 0; j < QPL; ++j) {
-                        const int iq = lane + WAVE * j;
-                        if (keep_new) nrow[WAVE * j] = nwv[j];
-                        d[j] = nwv[j] - ocur[j];
-                        dr[WAVE * j] = d[j];
-                        const double wd = lw[iq] * d[j];
-                        s1 += wd; s2 += lwI[iq] * d[j]; s3 += wd * d[j];
-                    }
-                    wave_sum3(s1, s2, s3);
-                    if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
-#pragma unroll
-                    for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
-                        if (p < P) {
-                            const double v = readlane_f64(prow[p], bl);
-                            if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
-                        }
-                    const int ov = __builtin_amdgcn_readlane(pov, bl);
-                    if (lane == 0) { povf[k] = ov; if (!keep_new) put_contrib(k, cnew); }
-                } else {
-                    PIPE_PIN_ROW(onext);
-                }
-#pragma unroll
-                for (int j = 0; j < QPL; ++j) ocur[j] = onext[j];
-                if ((l % RW) == RW - 1) {
-                    // my rows of this sub-window are written: count this wave in for the Gram waves
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) atomicAdd(&handoff[0], 1);
-                }
-            }
-        } else if (!(a.pad0 & 64)) {
-            const int gv = wave - 4;
-            double *gred0 = lds + pa.g.gram_off + 16;
-            const int tg = (W + 15) >> 4, nt = tg * (tg + 1) / 2;
-            bool ok = true;
-            for (int ss = 0; ss < nsb && ok; ++ss) {
-                const int sub = by * nsb + ss;
-                const int64_t left = max_iter - (w * Kb + (int64_t)sub * W);
-                const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
-                ok = pipe_spin_until(&handoff[0], 4 * (ss + 1));                      // the four row waves have stored sub-window ss
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if (ok && nvalid > 1)
-                    ok = pipe_gram_flag<QPL>(dwin + (size_t)sub * W * qpad, qpad, W, nvalid, lw, gred0 + (size_t)ss * 4 * nt * 256,
-                                             &handoff[1 + ss], glb(pa.gwin) + (((size_t)rep * 2 + buf) * Kb + (size_t)sub * W) * W, gv);
-            }
-            if (!ok && lane == 0) atomicOr(&pa.chains[rep].overflow, 2);              // reported as an error by the host, never a hang
-        }
-        return;
-    }
-
     if (pa.g.gram_lds) {
         // ---- sub-window by sub-window: every wave evaluates its W/8 rows of the sub-window (d also into the LDS row
         // buffer), barrier, the eight waves take the Gram block from LDS, next sub-window.  Only the LDS traffic is
@@ -733,24 +563,79 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
         const int nmine = nsb * RW;                                                    // my rows (<= 8), lane l <-> my l-th row
         const bool no_gram = a.pad0 & 64;                                              // diagnostic: no Gram blocks (uniform)
         const int lrow = (lane / RW) * W + wave * RW + (lane % RW);                     // its offset in the block
+        const bool lazy = pa.g.lazy_rows;
+        // ---- lazy rows: the block's stale `old` rows (their last proposal, N steps ago, was accepted: ~6 % of them) are
+        // evaluated again from the parameter set, one q per thread and row — an eighth of a wave's row time for the whole
+        // block, and no wave ends up with more rows than the others — and written back to the row cache.  Lanes 32 + l of
+        // a wave mirror its lanes l: the same rows, their `old` side — validity flag and parameter set in one round trip
+        // (under way while the proposals are drawn), and ONE prepare() call serves the proposals and the old sets.
+        constexpr int CON = 12;                                   // doubles per Contrib record in LDS
+        static_assert(sizeof(Contrib<M>) <= 8 * CON && sizeof(Contrib<M>) % 8 == 0, "Contrib record");
+        int32_t *stl = reinterpret_cast<int32_t *>(gred);         // [0] count (zeroed before the tables' barrier), then the stale contributions
+        double *scon = gred + 64;                                 // their Contrib records
         double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+        const int l2 = lane - 32;
+        const bool old_lane = lazy && l2 >= 0 && l2 < nmine;
+        int stale_r = -1;
+        if (old_lane) {
+            const int lrow_o = (l2 / RW) * W + wave * RW + (l2 % RW);
+            if (sb0 + lrow_o < max_iter) {
+                const int r = (int)((sb0 + lrow_o) % N);
+                const int v = row_valid[r];
+#pragma unroll
+                for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) if (p < P) prow[p] = rset[(size_t)r * P + p];
+                if (!v) stale_r = r;
+            }
+        }
         int pov = 0, my_oslot = 0, my_sslot = 0;
         {
+            const int r = (int)((sb0 + lrow) % N);
+            if (lane < nmine) {
+                if (lazy) my_oslot = r;
+                else { my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + by * BR + lrow]; }
+            }
             const int64_t sl = sb0 + lrow;
 #pragma unroll
             for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
                 if (p < P) {
                     double u = 0.5;
                     if (lane < nmine && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
-                    prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
+                    const double pv = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
+                    if (!(old_lane && sb0 + ((l2 / RW) * W + wave * RW + (l2 % RW)) < max_iter)) prow[p] = pv;
                 }
-            if (lane < nmine) {
-                const int r = (int)((sb0 + lrow) % N);
-                my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + by * BR + lrow];
-            }
         }
         Contrib<M> prop;
         prop.prepare(a.model, prow);
+        int nst = 0;
+        if (lazy) {
+            if (stale_r >= 0) {
+                const int e = atomicAdd(&stl[0], 1);
+                stl[1 + e] = stale_r;
+                double tmp[CON] = {};
+                __builtin_memcpy(tmp, &prop, sizeof(Contrib<M>));
+#pragma unroll
+                for (int i = 0; i < (int)(sizeof(Contrib<M>) / 8); ++i) scon[e * CON + i] = tmp[i];
+            }
+            PIPE_LDS_BARRIER();
+            nst = stl[0];
+            for (int i = 0; i < nst; ++i) {                       // (list order varies from run to run, the rows do not depend on it)
+                const int r = stl[1 + i];
+                Contrib<M> c;
+                {
+                    double tmp[CON];
+#pragma unroll
+                    for (int x = 0; x < (int)(sizeof(Contrib<M>) / 8); ++x) tmp[x] = scon[i * CON + x];
+                    __builtin_memcpy(&c, tmp, sizeof(Contrib<M>));
+                }
+#pragma unroll
+                for (int x = 0; x < QTB; ++x) {
+                    const int iq = tid + PIPE_BLOCK * x;
+                    if (iq < qpad) cache[(size_t)r * qpad + iq] = pipe_point_intensity<M>(c, lq[iq], lq3[iq], tab);
+                }
+                if (tid == 0) row_valid[r] = 1;
+            }
+            if (nst) __syncthreads();                             // the refreshed rows have landed before the row loop loads them (uniform)
+        }
         double ocur[QPL], onext[QPL];
         {
             const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
@@ -781,7 +666,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {
                         const int iq = lane + WAVE * j;
-                        if (keep_new) nrow[WAVE * j] = nwv[j];
+                        if (!lazy) nrow[WAVE * j] = nwv[j];
                         d[j] = nwv[j] - ocur[j];
                         dr[WAVE * j] = d[j];
                         dl[WAVE * j] = d[j];
@@ -797,7 +682,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
                             if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
                         }
                     const int ov = __builtin_amdgcn_readlane(pov, bl);
-                    if (lane == 0) { povf[k] = ov; if (!keep_new) put_contrib(k, cnew); }
+                    if (lane == 0) povf[k] = ov;
                 } else {
                     PIPE_PIN_ROW(onext);
                 }
@@ -903,7 +788,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
 #pragma unroll
         for (int j = 0; j < QPL; ++j) {
             const int iq = lane + WAVE * j;
-            if (keep_new) nrow[WAVE * j] = nwv[j];
+            nrow[WAVE * j] = nwv[j];
             d[j] = nwv[j] - ocur[j];
             dr[WAVE * j] = d[j];
             const double wd = lw[iq] * d[j];
@@ -918,7 +803,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
                 if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
             }
         const int ov = __builtin_amdgcn_readlane(pov, bl);
-        if (lane == 0) { povf[k] = ov; if (!keep_new) put_contrib(k, cnew); }
+        if (lane == 0) povf[k] = ov;
 #pragma unroll
         for (int j = 0; j < QPL; ++j) ocur[j] = onext[j];
         ri = (ri + 1 == N) ? 0 : ri + 1;
@@ -1255,38 +1140,23 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #endif
         if (wave == 0 && lane == 0) lacc[Kb] = num_acc_win;
         PIPE_LDS_BARRIER();
-        if constexpr (pipe_light_model(M)) {
-            // ---- the rows of the accepted steps, evaluated again from their Contrib records and stored into the row
-            // slots their contributions now own (the producers kept none of the window's `new` rows): off the
-            // decision path, one q per thread, records staged through the (now idle) row buffer
-            const int nacc = lacc[Kb];
-            if (pa.g.recompute_new && nacc > 0) {
-                const auto pcon = glb((const double *)pa.pcon) + ((size_t)rep * 2 + buf) * Kb * PIPE_CON_DOUBLES;
-                double *lrec = rowbuf;
-                for (int i = tid; i < nacc * PIPE_CON_DOUBLES; i += T)
-                    lrec[i] = pcon[(size_t)lacc[i / PIPE_CON_DOUBLES] * PIPE_CON_DOUBLES + (i % PIPE_CON_DOUBLES)];
-                PIPE_LDS_BARRIER();
-#pragma unroll
-                for (int x = 0; x < QT; ++x) {
-                    const int i = tid + T * x;
-                    if (i < qpad) {
-                        const double qq = glb(a.q)[i], q3 = 1.0 / (qq * qq * qq);     // as the producers' tables
-                        for (int n = 0; n < nacc; ++n) {
-                            Contrib<M> c;
-                            __builtin_memcpy(&c, lrec + (size_t)n * PIPE_CON_DOUBLES, sizeof(Contrib<M>));
-                            cache[(size_t)lslot[lacc[n]] * qpad + i] = pipe_point_intensity<M>(c, qq, q3);
-                        }
-                    }
-                }
-            }
-        }
         {   // write the window's slot tables back and store the accepted proposals (mcsas.py:381), all waves
             const int nacc = lacc[Kb];
             if (nacc > 0) {
-                for (int i = tid; i < kmax_all; i += T) {
-                    stage[i] = lstage[i];
-                    int r = ri0 + i; if (r >= N) r -= N;
-                    slot_of[r] = lslot[i];
+                if (!pa.g.lazy_rows) {
+                    for (int i = tid; i < kmax_all; i += T) {
+                        stage[i] = lstage[i];
+                        int r = ri0 + i; if (r >= N) r -= N;
+                        slot_of[r] = lslot[i];
+                    }
+                } else {
+                    // the accepted contributions' cached rows are stale from here on (the producer that proposes for them
+                    // next, N steps from now, evaluates them again from the parameters stored just below)
+                    auto row_valid = glb(pa.row_valid) + (size_t)rep * N;
+                    for (int i = tid; i < nacc; i += T) {
+                        int r = ri0 + lacc[i]; if (r >= N) r -= N;
+                        row_valid[r] = 0;
+                    }
                 }
                 for (int i = tid; i < nacc * P; i += T) {
                     const int kk = lacc[i / P], p = i % P;

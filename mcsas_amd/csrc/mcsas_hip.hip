@@ -348,8 +348,8 @@ struct mcsas_plan {
     int mode = MCSAS_EXEC_WAVE;
     PipeArgs pipe{};
     PipeChain *d_chains = nullptr;
-    double *d_ft = nullptr, *d_wft = nullptr, *d_dwin = nullptr, *d_gwin = nullptr, *d_scal = nullptr, *d_pcon = nullptr, *d_pval = nullptr;
-    int32_t *d_slot_of = nullptr, *d_stage = nullptr, *d_povf = nullptr;
+    double *d_ft = nullptr, *d_wft = nullptr, *d_dwin = nullptr, *d_gwin = nullptr, *d_scal = nullptr, *d_pval = nullptr;
+    int32_t *d_slot_of = nullptr, *d_stage = nullptr, *d_povf = nullptr, *d_row_valid = nullptr;
     uint64_t *d_timeline = nullptr;
     int32_t *h_done = nullptr;          // pinned + mapped: scan kernels count finished chains into it
     PipeArgs *d_pipeargs = nullptr;     // the argument block the tick kernels read (device copy)
@@ -398,7 +398,7 @@ extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     hipFree(pl->d_rset); hipFree(pl->d_cache); hipFree(pl->d_fit); hipFree(pl->d_replay); hipFree(pl->d_out);
     if (pl->h_stop) hipHostFree(pl->h_stop);
     if (pl->h_done) hipHostFree(pl->h_done);
-    hipFree(pl->d_pipeargs); hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_gwin); hipFree(pl->d_scal); hipFree(pl->d_pcon);
+    hipFree(pl->d_pipeargs); hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_gwin); hipFree(pl->d_scal); hipFree(pl->d_row_valid);
     hipFree(pl->d_timeline); hipFree(pl->d_pval); hipFree(pl->d_slot_of); hipFree(pl->d_stage); hipFree(pl->d_povf);
     for (int i = 0; i < mcsas_plan::RING; ++i) {
         if (pl->evP[i]) hipEventDestroy(pl->evP[i]);
@@ -460,8 +460,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     const int tab_shared = table_doubles_host(p->model_id, margs.int_div), tab_row = rowtab_doubles_host(p->model_id, margs.int_div);
     const bool heavy_rows = tab_shared > 0 || margs.smear_nk > 0;
     const int rpw_req = (p->reserved0 >> 8) & 15;          // tuning / diagnostics: rows per producer wave of the pipeline, 0 = automatic
-    const int split_req = (p->reserved0 >> 16) & 1;        // tuning: 1 = role-split producer blocks (row waves + Gram waves)
-    const int recompute_req = (p->reserved0 >> 17) & 1;    // tuning: 1 = producers store no `new` rows, the scan block re-evaluates the accepted ones (measured: no gain)
+    const int eager_req = (p->reserved0 >> 16) & 1;        // tuning: 1 = every proposal's `new` row is stored and row slots are swapped on acceptance (no lazy re-evaluation)
     const int gram_global_req = (p->reserved0 >> 18) & 1;  // tuning: 1 = Gram operands from the d rows in HBM/L2 (no LDS copy of the sub-window)
     const int sub_req = (p->reserved0 >> 12) & 15;         // tuning: cap on the scan sub-window, in units of 8 steps (0 = automatic)
 #define TABD(waves_per_block) (tab_shared + (waves_per_block) * tab_row)
@@ -477,7 +476,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             // one workgroup per chain up to ~400, one wavefront per chain beyond; rows that cost an integral
             // each keep the workgroup's seven producer waves per chain until the chains alone fill the SIMDs
             if (p->n_reps >= (heavy_rows ? 1024 : 448)) mode = MCSAS_EXEC_WAVE;
-            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, split_req, recompute_req, sub_req, gram_global_req, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
+            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
             else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
             else mode = MCSAS_EXEC_WAVE;
         }
@@ -524,7 +523,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: needs 2*window <= n_contrib and the window in LDS (nq=%d, n_contrib=%d, waves=%d)", p->nq, (int)N, waves); }
         cache_rows = (int)N + 2 * pl->wg.window;
     } else if (mode == MCSAS_EXEC_PIPELINE) {
-        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, split_req, recompute_req, sub_req, gram_global_req, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
+        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
         cache_rows = (int)N + 2 * pl->pipe.g.kb;
     }
     size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
@@ -583,7 +582,8 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         PCHK(hipMalloc(&pl->d_dwin, sizeof(double) * R * 2 * Kb * qpad));
         PCHK(hipMalloc(&pl->d_gwin, sizeof(double) * R * 2 * Kb * pa.g.w));
         PCHK(hipMalloc(&pl->d_scal, sizeof(double) * R * 2 * Kb * 4));
-        PCHK(hipMalloc(&pl->d_pcon, sizeof(double) * R * 2 * Kb * PIPE_CON_DOUBLES));
+        PCHK(hipMalloc(&pl->d_row_valid, sizeof(int32_t) * R * N));
+        PCHK(hipMemset(pl->d_row_valid, 0, sizeof(int32_t) * R * N));
         PCHK(hipMalloc(&pl->d_pval, sizeof(double) * R * 2 * Kb * MCSAS_MAX_ACTIVE));
         PCHK(hipMalloc(&pl->d_povf, sizeof(int32_t) * R * 2 * Kb));
         PCHK(hipMemset(pl->d_povf, 0, sizeof(int32_t) * R * 2 * Kb));
@@ -595,7 +595,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             PCHK(hipEventCreateWithFlags(&pl->evS[i], hipEventDisableTiming));
         pa.c = a;
         pa.chains = pl->d_chains; pa.ft = pl->d_ft; pa.wft = pl->d_wft; pa.slot_of = pl->d_slot_of;
-        pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.gwin = pl->d_gwin; pa.scal = pl->d_scal; pa.pcon = pl->d_pcon; pa.pval = pl->d_pval;
+        pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.gwin = pl->d_gwin; pa.scal = pl->d_scal; pa.row_valid = pl->d_row_valid; pa.pval = pl->d_pval;
         pa.povf = pl->d_povf; pa.n_done = d_done; pa.tick = 0;
         pa.timeline = nullptr; pa.timeline_tick = -100;
 #ifdef MCSAS_STAMPS

@@ -724,26 +724,25 @@ def test_more_than_4096_q_points_is_refused_loudly():
 
 
 def test_pipeline_tuning_variants_replay_the_reference():
-    """The alternative producer layout of the pipeline (four row waves + four Gram waves per block with LDS
-    hand-offs, tuning bit 16 of the diagnostic word) is kept for measurements: it replays the reference's
-    512 q x 400 contribution chain like the default layout does.  (Its Gram blocks are summed over four q ranges
-    instead of eight, so a free-running chain may take a different turn at a numerically tied step — replacing one
-    negligible sphere by another moves chi² by less than its rounding error — which is why the comparison is with
-    the reference, not with the default layout.)"""
-    # bit 16: role split; bit 17: producers keep no `new` rows, the scan block re-evaluates the accepted ones; bits 12-15:
-    # scan sub-window capped at 16 / 8 steps; bits 8-11: 8 / 4 / 2 rows per producer wave
-    for flags in (1 << 16, 1 << 17, (1 << 16) | (1 << 17), 2 << 12, 1 << 12, 8 << 8, 4 << 8, (2 << 8) | (1 << 17)):
+    """The pipeline's alternative layouts, selected by the tuning bits of the diagnostic word and kept for measurements,
+    replay the reference's 512 q x 400 contribution chain like the default does: `new` rows stored eagerly and row slots
+    swapped on acceptance instead of stale rows evaluated again (bit 16), Gram operands from HBM/L2 instead of the LDS copy
+    of the sub-window (bit 18), other sub-window sizes (bits 12-15) and rows per producer wave (bits 8-11).  (Their Gram
+    blocks are summed in different groupings, so two free-running chains may take different turns at a numerically tied
+    step — replacing one negligible sphere by another moves chi² by less than its rounding error — which is why every
+    variant is compared with the reference, not with the default layout.)"""
+    for flags in (1 << 16, 1 << 18, (1 << 16) | (1 << 18), 2 << 12, 1 << 12, (1 << 12) | (1 << 16), 8 << 8, 4 << 8, (2 << 8) | (1 << 18), 3 << 8):
         g, m, spec, st, ost = traj_setup("g4_sphere_q512_fixed.npz")
         st.exec_mode, st.debug_flags = engine.EXEC_PIPELINE, flags
         res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st, replay=g["stream"][None, :])
         assert res.num_iter[0] == int(g["res_num_iter"]) and res.num_moves[0] == int(g["res_num_moves"]), flags
         np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
         np.testing.assert_allclose(res.chisq[0], float(g["res_conval"]), rtol=1e-7)
-    # the re-evaluation path of the other models without an integral, against their reference replays
-    for name in ("g4_sphcs_q40.npz", "g4_gausschain_q40.npz", "g4_lmasphere_q40.npz", "g7_sphere_q100_smeared.npz"):
+    # the other models without an integral (their stale rows are re-evaluated too), eager and lazy, against their reference replays
+    for name, flags in [(n, f) for n in ("g4_sphcs_q40.npz", "g4_gausschain_q40.npz", "g4_lmasphere_q40.npz", "g7_sphere_q100_smeared.npz") for f in (0, 1 << 16)]:
         g, m, spec, st, ost = traj_setup(name)
         _, psm = traj_smearing(g)
-        st.exec_mode, st.debug_flags = engine.EXEC_PIPELINE, 1 << 17
+        st.exec_mode, st.debug_flags = engine.EXEC_PIPELINE, flags
         res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st, replay=g["stream"][None, :], smear=psm)
         assert res.num_moves[0] == int(g["res_num_moves"]), name
         np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
