@@ -112,6 +112,16 @@ struct PipeArgs {
     int32_t timeline_tick, pad1;
 };
 
+// What a workgroup needs in its first microsecond, passed BY VALUE (kernel-argument segment, scalar loads): reading these
+// through the argument block in device memory costs a dependent global round trip before the first useful load can be
+// issued — pointer, then data — on the critical path of every tick.
+struct PipeHot {
+    const double *q, *w, *wI;
+    PipeChain *chains;
+    int32_t n_reps, n_contrib, n_active, qpad, kb, prod_blocks_y, w_sub, pad;
+    int64_t max_iter;
+};
+
 // schedule records go through scalar global loads / stores (a struct copy out of an address-space-qualified
 // reference does not exist in C++)
 __device__ __forceinline__ PipeSnap load_snap(const PipeSnap *p) {
@@ -468,21 +478,21 @@ __device__ __forceinline__ void pipe_prod_gram_lds(const double *drows, int dstr
 }
 
 template <int M, int QPL>
-__device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds, int rep, int by, int gy, int t) {
+__device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHot &hot, double *lds, int rep, int by, int gy, int t) {
     const ChainArgs &a = pa.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int WPB = PIPE_BLOCK / 64;
-    const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad, Kb = pa.g.kb;
-    const int64_t max_iter = a.max_iter;                      // a local copy: a field of the argument block read inside the row loop is a global load + full wait per row
+    const int N = hot.n_contrib, P = hot.n_active, qpad = hot.qpad, Kb = hot.kb;
+    const int64_t max_iter = hot.max_iter;                    // (a field of the argument block read inside the row loop would be a global load + full wait per row)
     // the data tables do not depend on the chain's schedule record: both round trips run side by side
     constexpr int QTB = (QPL * 64 + PIPE_BLOCK - 1) / PIPE_BLOCK;
     double tq[QTB], tw[QTB], twI[QTB];
 #pragma unroll
     for (int x = 0; x < QTB; ++x) {
         const int i = tid + PIPE_BLOCK * x < qpad ? tid + PIPE_BLOCK * x : 0;
-        tq[x] = glb(a.q)[i]; tw[x] = glb(a.w)[i]; twI[x] = glb(a.wI)[i];
+        tq[x] = glb(hot.q)[i]; tw[x] = glb(hot.w)[i]; twI[x] = glb(hot.wI)[i];
     }
-    const PipeSnap sn = load_snap(&pa.chains[rep].snap[t & 1]);
+    const PipeSnap sn = load_snap(&hot.chains[rep].snap[t & 1]);
     if (!sn.alive || t < sn.t_init) return;
 
     double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
@@ -636,6 +646,8 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, double *lds,
             }
             if (nst) __syncthreads();                             // the refreshed rows have landed before the row loop loads them (uniform)
         }
+        // (requesting this row speculatively before the stale rows are known, and reading it again past the vector cache
+        // when it turns out stale, was measured: no gain)
         double ocur[QPL], onext[QPL];
         {
             const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
@@ -1265,13 +1277,13 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 // ------------------------------------------------------------------------------------ one tick
 // launch t: blocks [0, R) do SCAN(t) (skipped for t < 0), the others PROD(t + 1)
 template <int M, int QPL>
-__global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *pap, const int tick, const int stop_now) {
+__global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *pap, const int tick, const int stop_now, const PipeHot hot) {
     // The argument block lives in device memory and is read where it is needed: passed by value it
     // would sit in SGPRs for the whole kernel (600+ bytes) and the scan loop would run on spilled
     // scalars (one v_readlane per use).
     extern __shared__ double lds[];
     const PipeArgs &pa = *pap;
-    const int R = pa.c.n_reps, b = blockIdx.x, t = tick;
+    const int R = hot.n_reps, b = blockIdx.x, t = tick;
 #ifdef MCSAS_STAMPS
     struct Timeline {                                          // one record per wave, written when the wave leaves the kernel
         uint64_t *p, t0; uint32_t hw;
@@ -1286,7 +1298,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
     if (b < R) {
         if (t >= 0) {
             // rows per wave and sub-window: uniform for the launch; the host only picks combinations instantiated here
-            switch (pa.g.w >> 3) {
+            switch (hot.w_sub >> 3) {
 #define PIPE_SCAN_CASE(r) case r: if constexpr (r * QPL <= PIPE_MAX_ROW_DOUBLES) pipe_scan_block<M, QPL, r>(pa, lds, b, t, stop_now); break;
                 PIPE_SCAN_CASE(1) PIPE_SCAN_CASE(2) PIPE_SCAN_CASE(3) PIPE_SCAN_CASE(4) PIPE_SCAN_CASE(6) PIPE_SCAN_CASE(8)
 #undef PIPE_SCAN_CASE
@@ -1299,10 +1311,10 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
         // congruent to r modulo 8, i.e. on the XCD of its scan block, so that next tick's d rows sit in that
         // XCD's L2) measured 10-40 % SLOWER on config 2: 50 chains x (1 + gy) blocks do not divide over 8 XCDs of
         // 32 CUs with one block per CU — two XCDs get 35 blocks and their chains take two rounds.
-        const int gy = pa.g.prod_blocks_y;
+        const int gy = hot.prod_blocks_y;
         int rep = (b - R) / gy, y = (b - R) % gy;
         if (pa.c.pad0 & 128) { const int x = b & 7, j = (b - R) >> 3; rep = x + 8 * (j / gy); y = j % gy; }
-        if (rep < R) pipe_prod_block<M, QPL>(pa, lds, rep, y, gy, t + 1);
+        if (rep < R) pipe_prod_block<M, QPL>(pa, hot, lds, rep, y, gy, t + 1);
     }
 }
 

@@ -646,6 +646,10 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     const long long max_ticks = (win_per_attempt >= TICK_CAP / attempts) ? TICK_CAP : std::min(attempts * win_per_attempt + 4, TICK_CAP);
     // scan blocks + producer blocks (chain-major; 8 XCD classes of ceil(R/8) chains each with diagnostic bit 128)
     const dim3 grid((pl->args.pad0 & 128) ? R + 8 * ((R + 7) / 8) * pa.g.prod_blocks_y : R + R * pa.g.prod_blocks_y);
+    PipeHot hot{};
+    hot.q = pa.c.q; hot.w = pa.c.w; hot.wI = pa.c.wI; hot.chains = pa.chains;
+    hot.n_reps = pa.c.n_reps; hot.n_contrib = pa.c.n_contrib; hot.n_active = pa.c.model.n_active; hot.qpad = pa.c.qpad;
+    hot.kb = pa.g.kb; hot.prod_blocks_y = pa.g.prod_blocks_y; hot.w_sub = pa.g.w; hot.max_iter = pa.c.max_iter;
     long long t = -1;                                    // launch t = {SCAN(t), PROD(t+1)}
     for (; t < max_ticks; ++t) {
         if (t >= mcsas_plan::RING && (t % 16) == 0) {
@@ -655,7 +659,7 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
             if (*(volatile int32_t *)pl->h_done >= R) break;
         }
         int32_t tk = (int32_t)t, stop_now = (pl->prob.stop && *(volatile int32_t *)pl->prob.stop) ? 1 : 0;
-        void *ka[] = {(void *)&pl->d_pipeargs, (void *)&tk, (void *)&stop_now};
+        void *ka[] = {(void *)&pl->d_pipeargs, (void *)&tk, (void *)&stop_now, (void *)&hot};
         HIPCHK(hipLaunchKernel(tick, grid, dim3(PIPE_BLOCK), ka, lds, st));
         if (t >= 0 && (t % 16) == 0) HIPCHK(hipEventRecord(pl->evS[(t / 16) % mcsas_plan::RING], st));
     }
