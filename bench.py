@@ -253,7 +253,7 @@ def main():
             raise SystemExit("strong scaling: %d repetitions cannot be sharded over %d ranks" % (n_total, world))
         first, reps = mdist.shard_reps(n_total, world, rank)
     mc_steps = args.mc_steps or {2: 20000, 3: 2000, 4: 1000, 5: 1000}[args.config]
-    lps = args.launches_per_step or (36 if args.config == 2 and not dry else 1)
+    lps = args.launches_per_step or (40 if args.config == 2 and not dry else 1)
     setup = model.setup()
     if dry:
         plan = DryPlan(ncontrib, setup.n_active, len(q), reps)
