@@ -13,7 +13,7 @@
 namespace mcsas {
 
 template <int M, int QPL, bool CACHE>
-__global__ __launch_bounds__(64) void chain_wave_kernel(const ChainArgs a) {
+__global__ __launch_bounds__(64, (QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1) void chain_wave_kernel(const ChainArgs a) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int rep = blockIdx.x;
