@@ -2,17 +2,19 @@
 // with fewer chains than CUs (BASELINE config 2: 50 chains on 256 CUs).
 //
 // One launch per "tick" t (pipe_tick_kernel), two kinds of workgroup in its grid:
-//   producer blocks (every CU) do PROD(t+1): the form-factor rows of the NEXT window of Kb steps per chain.
-//       A block owns one SUB-WINDOW of W = 8 * rows_per_wave consecutive steps: `new` row into a spare HBM
-//       row slot, d = new - old and the three ft-independent sums (a = Σ w d, e = Σ wI d, g = Σ w d²) into the
-//       window buffer, and then — fp64 MFMA, v_mfma_f64_16x16x4_f64 — the sub-window's Gram block
-//       G[a][k] = Σ_q w d_a d_k, which does not depend on ft either.
+//   producer blocks (four per chain at config 2) do PROD(t+1): the form-factor rows of the NEXT window of Kb steps.
+//       A block owns 8 * rows_per_wave consecutive steps = one or more SUB-WINDOWS of W steps: per step
+//       d = new - old to the window buffer, the three ft-independent sums (a = Σ w d, e = Σ wI d, g = Σ w d²),
+//       and — fp64 MFMA, v_mfma_f64_16x16x4_f64 — the sub-window's Gram block G[a][k] = Σ_q w d_a d_k, which does
+//       not depend on ft either.  Rows without an integral: the sub-window's d rows stay in LDS for the MFMAs, no
+//       `new` row is stored and a contribution's cached row is evaluated again when it has gone stale (lazy rows);
+//       rows with an integral: `new` row into a spare HBM row slot, slots swapped on acceptance.
 //   scan blocks (one per chain) do SCAN(t): per sub-window ONE pass over its d rows gives h_k = Σ (w ft) d_k for
 //       the ft the sub-window starts from (eight waves, rows streamed HBM/L2 -> registers); then ONE wave takes
 //       the W decisions with lane g = step g: a candidate's fit sums are SC + a, SIC + e, SCC + 2h + g, and after
 //       an accepted row `acc` the later steps of the sub-window need only h_k += G[acc][k] (one LDS read) — no
 //       barrier, no re-reduction and no restart per accepted move; the accepted rows are applied to ft once per
-//       sub-window, in order, as (ft - old) + new like mcsas.py:367.
+//       sub-window, in order, as ft += d.
 // PROD(t+1) and SCAN(t) run concurrently inside one launch because a window's rows depend only on the random
 // stream and on row slots settled two windows earlier (2*Kb <= N), never on the decisions of the window
 // before.  Launch t+1 follows launch t on the same stream: the kernel boundary is the only synchronisation
@@ -555,7 +557,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     }
 
     if (a.pad0 & 16) return;                                  // diagnostic: no window rows
-    if (pa.g.gram_lds) {
+    if constexpr (pipe_light_model(M)) if (pa.g.gram_lds) {        // (rows with an integral never take this path: not instantiated for them)
         // ---- sub-window by sub-window: every wave evaluates its W/8 rows of the sub-window (d also into the LDS row
         // buffer), barrier, the eight waves take the Gram block from LDS, next sub-window.  Only the LDS traffic is
         // waited for at the barriers: the rows' global stores drain behind the MFMAs.
@@ -574,6 +576,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         const bool no_gram = a.pad0 & 64;                                              // diagnostic: no Gram blocks (uniform)
         const int lrow = (lane / RW) * W + wave * RW + (lane % RW);                     // its offset in the block
         const bool lazy = pa.g.lazy_rows;
+        PIPE_TLX_MARK(pa, t, 0);
         // ---- lazy rows: the block's stale `old` rows (their last proposal, N steps ago, was accepted: ~6 % of them) are
         // evaluated again from the parameter set, one q per thread and row — an eighth of a wave's row time for the whole
         // block, and no wave ends up with more rows than the others — and written back to the row cache.  Lanes 32 + l of
@@ -616,6 +619,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         }
         Contrib<M> prop;
         prop.prepare(a.model, prow);
+        PIPE_TLX_MARK(pa, t, 1);
         int nst = 0;
         if (lazy) {
             if (stale_r >= 0) {
@@ -646,6 +650,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
             }
             if (nst) __syncthreads();                             // the refreshed rows have landed before the row loop loads them (uniform)
         }
+        PIPE_TLX_MARK(pa, t, 2);
         // (requesting this row speculatively before the stale rows are known, and reading it again past the vector cache
         // when it turns out stale, was measured: no gain)
         double ocur[QPL], onext[QPL];
@@ -655,6 +660,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
             for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
         }
         PIPE_PIN_ROW(ocur);                                       // (a pending load carried into the loop would be waited for at its head, every iteration)
+        PIPE_TLX_MARK(pa, t, 3);
         for (int ss = 0; ss < nsb; ++ss) {
             for (int jr = 0; jr < RW; ++jr) {
                 const int l = ss * RW + jr, bl = __builtin_amdgcn_readfirstlane(l);
