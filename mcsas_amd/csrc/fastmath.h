@@ -221,23 +221,25 @@ MCSAS_HD double rsqrt_fast(double x) {
 // J1(x) for 0 < x < 2^20 with 1/x supplied by the caller (the integration loops have it as a product
 // of two precomputed reciprocals): same Cephes rationals as j1_fast, one division per branch, the
 // branch-free sincos core and the hardware reciprocal square root.
-MCSAS_HD double j1_core(double x, double invx) {
-    if (x <= 5.0) {
-        const double z = x * x;
-        double n = -8.99971225705559398224E8;
-        n = fma(n, z, 4.52228297998194034323E11);
-        n = fma(n, z, -7.27494245221818276015E13);
-        n = fma(n, z, 3.68295732863852883286E15);
-        double d = z + 6.20836478118054335476E2;
-        d = fma(d, z, 2.56987256757748830383E5);
-        d = fma(d, z, 8.35146791431949253037E7);
-        d = fma(d, z, 2.21511595479792499675E10);
-        d = fma(d, z, 4.74914122079991414898E12);
-        d = fma(d, z, 7.84369607876235854894E14);
-        d = fma(d, z, 8.95222336184627338078E16);
-        d = fma(d, z, 5.32278620332680085395E18);
-        return div_fast(n * x * (z - 1.46819706421238932572E1) * (z - 4.92184563216946036703E1), d);
-    }
+// the two ranges of j1_core as functions of their own: a caller that knows (wave-uniformly) which range a group of its
+// arguments is in can run several of them interleaved in one basic block
+MCSAS_HD double j1_core_small(double x) {                   // x <= 5
+    const double z = x * x;
+    double n = -8.99971225705559398224E8;
+    n = fma(n, z, 4.52228297998194034323E11);
+    n = fma(n, z, -7.27494245221818276015E13);
+    n = fma(n, z, 3.68295732863852883286E15);
+    double d = z + 6.20836478118054335476E2;
+    d = fma(d, z, 2.56987256757748830383E5);
+    d = fma(d, z, 8.35146791431949253037E7);
+    d = fma(d, z, 2.21511595479792499675E10);
+    d = fma(d, z, 4.74914122079991414898E12);
+    d = fma(d, z, 7.84369607876235854894E14);
+    d = fma(d, z, 8.95222336184627338078E16);
+    d = fma(d, z, 5.32278620332680085395E18);
+    return div_fast(n * x * (z - 1.46819706421238932572E1) * (z - 4.92184563216946036703E1), d);
+}
+MCSAS_HD double j1_core_large(double x, double invx) {      // x > 5
     const double w = 5.0 * invx, z = w * w;
     double pn = 7.62125616208173112003E-4;
     pn = fma(pn, z, 7.31397056940917570436E-2);
@@ -273,6 +275,10 @@ MCSAS_HD double j1_core(double x, double invx) {
     // (pn/pd) cs - w (qn/qd) sn over one common denominator
     const double num = (pn * qd) * cs - (w * (qn * pd)) * sn;
     return div_fast(num, pd * qd) * (0.79788456080286535588 * rsqrt_fast(x));
+}
+MCSAS_HD double j1_core(double x, double invx) {
+    if (x <= 5.0) return j1_core_small(x);
+    return j1_core_large(x, invx);
 }
 
 }  // namespace mcsas

@@ -165,27 +165,60 @@ template <> struct Contrib<MCSAS_MODEL_CYL_ISO> {
         }
     }
     // same integral as intensity(): f_k = J1(q A_k) sin(q B_k) / (q^2 2 A_k B_k), without divisions
-    // or large-argument branches in the loop (valid when `fast`); orientation loop outside, the
-    // lane's QPL q values inside
+    // or large-argument branches in the loop (valid when `fast`).  One q slot of the lane at a time, the orientations in
+    // groups of seven: J1 changes formula at x = 5, and with x = q A_k varying slowly along k a whole group — all 64 lanes,
+    // whose q lie within a factor two of each other — is nearly always on one side, so the side is chosen once per
+    // group (wave-uniform) and its evaluations run interleaved in one basic block.  (The earlier form — all q slots
+    // of the lane inside the k loop, J1's branch per evaluation — reached 0.63 of the fp64 issue rate: eight
+    // data-dependent branches per k cut the loop body into blocks that cannot overlap.)  The sum over k is taken in the
+    // same order as before: same bits.
     template <int QPL>
     __device__ __forceinline__ void rows_rt(const QTables &t, int lane, double (&out)[QPL]) const {
         double q[QPL], invq[QPL], acc[QPL];
 #pragma unroll
-        for (int j = 0; j < QPL; ++j) {
-            q[j] = t.q[lane + WAVE * j];
-            invq[j] = (q[j] * q[j]) * t.q3inv[lane + WAVE * j];
-            acc[j] = 0.;
-        }
+        for (int j = 0; j < QPL; ++j) { q[j] = 0.; invq[j] = 0.; acc[j] = 0.; }
         const double *rt = t.rowtab;
-        for (int k = 1; k < K - 1; ++k) {
-            const double A = rt[4 * k], B = rt[4 * k + 1], C = rt[4 * k + 2], iA = rt[4 * k + 3];
+        constexpr int G = 7;                                  // (K = 100: 98 interior orientations = 14 groups; groups of 4: 2 % slower)
+#pragma nounroll
+        for (int js = 0; js < QPL; ++js) {
+            const double qj = t.q[lane + WAVE * js];
+            const double iqj = (qj * qj) * t.q3inv[lane + WAVE * js];
+            double a = 0.;
+            int k = 1;
+            for (; k + G <= K - 1; k += G) {
+                double A[G], B[G], C[G], iA[G], x[G], jv[G], sl[G], cl[G];
+                bool all_gt = true, all_le = true;
 #pragma unroll
-            for (int j = 0; j < QPL; ++j) {
-                double sl, cl;
-                sincos_core(q[j] * B, &sl, &cl);
-                const double g = (j1_core(q[j] * A, invq[j] * iA) * sl) * C;
-                acc[j] = fma(g, g, acc[j]);
+                for (int g = 0; g < G; ++g) {
+                    A[g] = rt[4 * (k + g)]; B[g] = rt[4 * (k + g) + 1]; C[g] = rt[4 * (k + g) + 2]; iA[g] = rt[4 * (k + g) + 3];
+                    x[g] = qj * A[g];
+                    all_gt = all_gt && x[g] > 5.0; all_le = all_le && x[g] <= 5.0;
+                }
+                if (__all(all_gt)) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) { sincos_core(qj * B[g], &sl[g], &cl[g]); jv[g] = j1_core_large(x[g], iqj * iA[g]); }
+                } else if (__all(all_le)) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) { sincos_core(qj * B[g], &sl[g], &cl[g]); jv[g] = j1_core_small(x[g]); }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) { sincos_core(qj * B[g], &sl[g], &cl[g]); jv[g] = j1_core(x[g], iqj * iA[g]); }
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const double gg = (jv[g] * sl[g]) * C[g];
+                    a = fma(gg, gg, a);
+                }
             }
+            for (; k < K - 1; ++k) {
+                const double A = rt[4 * k], B = rt[4 * k + 1], C = rt[4 * k + 2], iA = rt[4 * k + 3];
+                double s1, c1;
+                sincos_core(qj * B, &s1, &c1);
+                const double gg = (j1_core(qj * A, iqj * iA) * s1) * C;
+                a = fma(gg, gg, a);
+            }
+#pragma unroll
+            for (int j = 0; j < QPL; ++j) if (j == js) { q[j] = qj; invq[j] = iqj; acc[j] = a; }
         }
 #pragma unroll
         for (int j = 0; j < QPL; ++j) {
