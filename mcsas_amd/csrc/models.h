@@ -431,6 +431,9 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
             const double z0 = fmin(x, 2.0);
             const int n = (int)ceil(z0 / fmin(1.0, 8.0 / F));
             const double h = z0 / (double)n, hw = 0.5 * h;
+            // (F z < 2^20 for every lane of the wave — in practice always —: the branch-free sincos, 1.8e-16 absolute, lets the
+            // unrolled points overlap)
+            const bool small_arg = __all(F * z0 < 1048576.0);
             for (int pnl = 0; pnl < n; ++pnl) {
                 const double mid = ((double)pnl + 0.5) * h;
                 double pa = 0.;
@@ -438,9 +441,12 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
                 for (int i = 0; i < 16; ++i) {
                     const double z = fma(hw, tab[i], mid);
                     double sn, cs;
-                    sincos_fast(F * z, &sn, &cs);
-                    const double E = exp(-z);
-                    const double fz = (sn * invF) * (2. * E / (-expm1(-2. * z)));
+                    if (small_arg) sincos_core(F * z, &sn, &cs);
+                    else sincos_fast(F * z, &sn, &cs);
+                    // 1/sinh z = 2 e^{-z} / (1 - e^{-2z}) from ONE expm1: u = e^{-z} - 1, e^{-z} = 1 + u, 1 - e^{-2z} = -u (2 + u)
+                    // (no cancellation for small z; one transcendental call per point instead of two)
+                    const double u = expm1(-z);
+                    const double fz = (sn * invF) * div_fast(2. * (1.0 + u), -u * (2.0 + u));
                     pa = fma(tab[16 + i], fz * (1.0 - z * invx), pa);
                 }
                 acc = fma(pa, hw, acc);
