@@ -144,7 +144,7 @@ constexpr int PIPE_DROW_PAD = 8;         // LDS d rows: stride qpad + 8 doubles,
 constexpr int PIPE_MAX_ROW_DOUBLES = 32;   // scan block: doubles per lane held in row registers (rows per wave and sub-window x q per lane)   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
-static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int sub_req, int gram_global_req, int eager_req, PipeGeom *g) {
+static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int sub_req, int gram_global_req, int eager_req, int n_chains, int n_cus, PipeGeom *g) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
@@ -164,6 +164,19 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         if (2 * 8 * rpw > n_contrib) return 1;
         by = n_contrib / (2 * 8 * rpw);
         if (by * 8 * rpw > 256) by = 256 / (8 * rpw);
+        // Rows with an integral: a block's time is one row per wave whatever the window, and the launch takes
+        // ceil(blocks / CUs) such rounds — the producer blocks per chain that give the most steps per round win
+        // (13 Kholodenko chains: 18 blocks per chain = 247 blocks in ONE round and 144 steps, instead of 32 = 429
+        // blocks in two rounds for 256)
+        if (heavy_rows && rows_per_wave_req == 0 && n_chains > 0 && n_cus > 0) {
+            int best = by; double best_rate = 0.;
+            for (int b = 1; b <= by; ++b) {
+                const int rounds = (n_chains * (b + 1) + n_cus - 1) / n_cus;
+                const double rate = (double)(b * 8 * rpw) / rounds;
+                if (rate >= best_rate) { best_rate = rate; best = b; }
+            }
+            by = best;
+        }
     } else {
         static const int order[6] = {6, 8, 4, 3, 2, 1};
         int kbs[6], best_kb = 0;

@@ -459,6 +459,8 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
     const int tab_shared = table_doubles_host(p->model_id, margs.int_div), tab_row = rowtab_doubles_host(p->model_id, margs.int_div);
     const bool heavy_rows = tab_shared > 0 || margs.smear_nk > 0;
+    int n_cus = 256;
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, pl->dev) == hipSuccess && v > 0) n_cus = v; }
     const int rpw_req = (p->reserved0 >> 8) & 15;          // tuning / diagnostics: rows per producer wave of the pipeline, 0 = automatic
     const int eager_req = (p->reserved0 >> 16) & 1;        // tuning: 1 = every proposal's `new` row is stored and row slots are swapped on acceptance (no lazy re-evaluation)
     const int gram_global_req = (p->reserved0 >> 18) & 1;  // tuning: 1 = Gram operands from the d rows in HBM/L2 (no LDS copy of the sub-window)
@@ -476,7 +478,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             // one workgroup per chain up to ~400, one wavefront per chain beyond; rows that cost an integral
             // each keep the workgroup's seven producer waves per chain until the chains alone fill the SIMDs
             if (p->n_reps >= (heavy_rows ? 1024 : 448)) mode = MCSAS_EXEC_WAVE;
-            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
+            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
             else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
             else mode = MCSAS_EXEC_WAVE;
         }
@@ -523,7 +525,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: needs 2*window <= n_contrib and the window in LDS (nq=%d, n_contrib=%d, waves=%d)", p->nq, (int)N, waves); }
         cache_rows = (int)N + 2 * pl->wg.window;
     } else if (mode == MCSAS_EXEC_PIPELINE) {
-        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
+        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
         cache_rows = (int)N + 2 * pl->pipe.g.kb;
     }
     size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
