@@ -188,6 +188,19 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
             if (kbs[c] > best_kb) best_kb = kbs[c];
         }
         if (best_kb == 0) return 1;
+        // Few chains: more, smaller producer blocks per chain shorten the producers' critical path (start-up + rows
+        // per wave + Gram) down to where the scan block becomes the longer one — as long as every block still gets a
+        // CU of its own.  Measured at 512 q x 400 (tools/sweep_rpw.sh): 3 rows per wave 3.1-3.3 ms per launch up to 28
+        // chains, 4 rows 3.3-3.6 ms up to 36, 6 rows 3.8-4.0 ms up to 51.
+        if (n_chains > 0 && n_cus > 0) {
+            static const int small_first[6] = {3, 4, 6, 8, 2, 1};
+            for (int c = 0; c < 6 && !rpw; ++c) {
+                const int r = small_first[c];
+                int b = (2 * 8 * r > n_contrib) ? 0 : n_contrib / (2 * 8 * r);
+                if (b * 8 * r > 256) b = 256 / (8 * r);
+                if (b > 0 && 20 * (b * 8 * r) >= 17 * best_kb && n_chains * (b + 1) <= n_cus) { rpw = r; by = b; }
+            }
+        }
         for (int c = 0; c < 6 && !rpw; ++c)                   // a window within 15 % of the largest is as good
             if (kbs[c] > 0 && 20 * kbs[c] >= 17 * best_kb) { rpw = order[c]; by = kbs[c] / (8 * rpw); }
     }
