@@ -221,6 +221,31 @@ MCSAS_HD double rsqrt_fast(double x) {
 // J1(x) for 0 < x < 2^20 with 1/x supplied by the caller (the integration loops have it as a product
 // of two precomputed reciprocals): same Cephes rationals as j1_fast, one division per branch, the
 // branch-free sincos core and the hardware reciprocal square root.
+// exp(x) - 1 for x <= 0 (the worm-like chain quadrature calls it with x = -z, 0 < z <= 2, once per point):
+// x = k ln2 + r with |r| <= ln2 / 2 (two-term Cody-Waite), expm1(r) by its Taylor polynomial to r^13 (next term
+// < 5e-18 relative), and e^x - 1 = (2^k - 1) + 2^k expm1(r) — both summands are exact scalings / differences, so
+// there is no cancellation for any k <= 0 (k = 0: the polynomial itself).  Branch-free, <= 2 ulp (tests/test_fastmath.py).
+MCSAS_HD double expm1_neg_fast(double x) {
+    const double k = rint(x * 1.44269504088896338700e+00);
+    double r = fma(-k, 6.93147180369123816490e-01, x);        // ln2 hi (fdlibm split)
+    r = fma(-k, 1.90821492927058770002e-10, r);               // ln2 lo
+    double p = 1.6059043836821613e-10;                        // 1/13!
+    p = fma(p, r, 2.08767569878680990e-09);                   // 1/12!
+    p = fma(p, r, 2.50521083854417188e-08);                   // 1/11!
+    p = fma(p, r, 2.75573192239858907e-07);                   // 1/10!
+    p = fma(p, r, 2.75573192239858907e-06);                   // 1/9!
+    p = fma(p, r, 2.48015873015873016e-05);                   // 1/8!
+    p = fma(p, r, 1.98412698412698413e-04);                   // 1/7!
+    p = fma(p, r, 1.38888888888888894e-03);                   // 1/6!
+    p = fma(p, r, 8.33333333333333322e-03);                   // 1/5!
+    p = fma(p, r, 4.16666666666666644e-02);                   // 1/4!
+    p = fma(p, r, 1.66666666666666657e-01);                   // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p * r, r, r);                                     // r + r² (1/2 + r/6 + ...)
+    const double e = ldexp(1.0, (int)k);                      // 2^k, exact (k >= -1075: 0 below that, result -1)
+    return fma(e, p, e - 1.0);
+}
+
 // the two ranges of j1_core as functions of their own: a caller that knows (wave-uniformly) which range a group of its
 // arguments is in can run several of them interleaved in one basic block
 MCSAS_HD double j1_core_small(double x) {                   // x <= 5

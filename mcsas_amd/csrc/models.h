@@ -445,7 +445,7 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
                     else sincos_fast(F * z, &sn, &cs);
                     // 1/sinh z = 2 e^{-z} / (1 - e^{-2z}) from ONE expm1: u = e^{-z} - 1, e^{-z} = 1 + u, 1 - e^{-2z} = -u (2 + u)
                     // (no cancellation for small z; one transcendental call per point instead of two)
-                    const double u = expm1(-z);
+                    const double u = expm1_neg_fast(-z);
                     const double fz = (sn * invF) * div_fast(2. * (1.0 + u), -u * (2.0 + u));
                     pa = fma(tab[16 + i], fz * (1.0 - z * invx), pa);
                 }
@@ -496,9 +496,9 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
 #pragma unroll 4
                 for (int i = 0; i < 16; ++i) {
                     const double z = fma(hw, tab[i], mid);
-                    const double den = -expm1(-2. * z);
+                    const double den = -expm1_neg_fast(-2. * z);
                     // sinh(e z)/(e sinh z) = exp(-(1-e) z) (1 - exp(-2 e z)) / (e (1 - exp(-2 z))); e -> 0: 2 z exp(-z)/(1-exp(-2z))
-                    const double fz = (e > 0.) ? exp(-a1 * z) * (-expm1(-2. * e * z)) / (e * den)
+                    const double fz = (e > 0.) ? exp(-a1 * z) * (-expm1_neg_fast(-2. * e * z)) / (e * den)
                                                : 2. * z * exp(-z) / den;
                     pa = fma(tab[16 + i], fz * (1.0 - z * invx), pa);
                 }

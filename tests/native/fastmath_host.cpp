@@ -10,6 +10,10 @@ void fm_sincos_core(int n, const double *x, double *s, double *c) { for (int i =
 void fm_j1_fast(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = mcsas::j1_fast(x[i]); }
 void fm_j1_core(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = mcsas::j1_core(x[i], 1.0 / x[i]); }
 void fm_div_fast(int n, const double *a, const double *b, double *y) { for (int i = 0; i < n; ++i) y[i] = mcsas::div_fast(a[i], b[i]); }
+void fm_expm1_neg_fast(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = mcsas::expm1_neg_fast(x[i]); }
+void fm_ref_expm1(int n, const double *x, double *hi, double *lo) {
+    for (int i = 0; i < n; ++i) { const long double q = expm1l((long double)x[i]); hi[i] = (double)q; lo[i] = (double)(q - (long double)hi[i]); }
+}
 void fm_rsqrt_fast(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = mcsas::rsqrt_fast(x[i]); }
 // references in x87 extended precision (64-bit significand): error 2^-64 relative, far below half an ulp of double
 void fm_ref_sincos(int n, const double *x, double *s_hi, double *s_lo, double *c_hi, double *c_lo) {

@@ -147,3 +147,19 @@ def test_div_and_rsqrt(lib):
     lib.fm_rsqrt_fast(len(x), P(x), P(y))
     lib.fm_ref_rsqrt(len(x), P(x), P(hi), P(lo))
     assert (np.abs((y - hi) - lo) / ulp_of(hi)).max() <= 1.5
+
+
+def test_expm1_neg_fast(lib):
+    """expm1_neg_fast (x <= 0; the Kholodenko quadrature's one transcendental per point besides sincos): <= 2 ulp
+    against x87 expm1l from -1e-300 down to -60, including the arguments next to the k ln2 / 2 seams and the tiny
+    ones where exp(x) - 1 would cancel."""
+    rs = np.random.RandomState(4)
+    seams = (np.arange(1, 80) * 0.5 * np.log(2.0))
+    x = -np.concatenate([rs.uniform(0, 2.5, 600000), 10 ** rs.uniform(-300, 0, 200000), rs.uniform(2, 60, 200000),
+                         seams, np.nextafter(seams, 0), np.nextafter(seams, 100), [0.0, 1e-320, 745.0, 800.0]])
+    x = np.ascontiguousarray(x)
+    y, hi, lo = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+    lib.fm_expm1_neg_fast(len(x), P(x), P(y))
+    lib.fm_ref_expm1(len(x), P(x), P(hi), P(lo))
+    err = np.abs((y - hi) - lo) / np.maximum(ulp_of(hi), 5e-324)
+    assert err.max() <= 2.0, (err.max(), x[np.argmax(err)])
