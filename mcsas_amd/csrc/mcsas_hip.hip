@@ -474,10 +474,12 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         else if (waves > 1) mode = MCSAS_EXEC_WORKGROUP;
         else {
             PipeGeom pg; WgGeom wgm;
-            // measured crossovers (tools/mode_sweep.py, sphere 512 q x 400): the pipeline wins up to ~128 chains,
-            // one workgroup per chain up to ~400, one wavefront per chain beyond; rows that cost an integral
-            // each keep the workgroup's seven producer waves per chain until the chains alone fill the SIMDs
-            if (p->n_reps >= (heavy_rows ? 1024 : 448)) mode = MCSAS_EXEC_WAVE;
+            // measured crossovers (tools/mode_sweep.py, sphere 512 q x 400, round 2: pipeline 2.4-2.6e8 steps/s up to
+            // 128 chains, workgroup per chain 2.4 / 2.9 / 3.3e8 at 128 / 192 / 256, wavefront per chain 2.4 / 3.1 / 4.7e8
+            // at 384 / 512 / 1024): the pipeline up to 128 chains, one workgroup per chain below 384, one wavefront per
+            // chain from there; rows that cost an integral each keep the workgroup's seven producer waves per chain
+            // until the chains alone fill the SIMDs
+            if (p->n_reps >= (heavy_rows ? 1024 : 384)) mode = MCSAS_EXEC_WAVE;
             else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
             else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
             else mode = MCSAS_EXEC_WAVE;
