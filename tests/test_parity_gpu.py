@@ -746,3 +746,29 @@ def test_pipeline_tuning_variants_replay_the_reference():
         res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st, replay=g["stream"][None, :], smear=psm)
         assert res.num_moves[0] == int(g["res_num_moves"]), name
         np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
+
+
+def test_pipeline_geometry_follows_the_chain_count():
+    """The pipeline's window is chosen with the chain count and the CU count in hand (chain_pipe.h: pipe_geometry):
+    rows without an integral get more, smaller producer blocks per chain while every block still has a CU of its own
+    (the window stays 192 steps at 512 q x 400 contributions: 3 / 4 / 6 rows per producer wave), rows with an integral
+    the number of producer blocks that gives the most steps per round of CUs.  Pinned here on a 256-CU MI355X."""
+    import mcsas_amd
+    from bench import synthetic_data
+    q, I, sig = synthetic_data(512)
+    m = mcsas_amd.Sphere()
+    m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
+    for reps in (1, 28, 36, 50, 100):
+        st = engine.Settings(n_contrib=400, n_reps=reps, max_iter=100, conv_crit=0.0, max_retries=0, seed=1, exec_mode=engine.EXEC_PIPELINE)
+        plan = engine.Plan(m.setup(), q, I, sig, st)
+        assert plan.info["exec_mode"] == "pipeline" and plan.info["window"] == 192, (reps, plan.info)
+        plan.close()
+    # Kholodenko, 600 contributions: 13 chains -> 18 producer blocks per chain (247 blocks, one round): window 144;
+    # 50 chains -> 29 blocks per chain (1500 blocks, 5.9 rounds): window 232
+    g = load("g9_kho_q512.npz")
+    mk, _ = make_models("kholodenko", g["spec_lo"], g["spec_hi"])
+    for reps, window in ((13, 144), (50, 232)):
+        st = engine.Settings(n_contrib=600, n_reps=reps, max_iter=10, conv_crit=0.0, max_retries=0, seed=1, exec_mode=engine.EXEC_PIPELINE)
+        plan = engine.Plan(mk.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st)
+        assert plan.info["window"] == window, (reps, plan.info)
+        plan.close()
