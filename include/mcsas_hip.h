@@ -108,7 +108,7 @@ typedef struct mcsas_problem {
     int32_t  reserved0;          /* 0.  (Measurement builds only: tuning / ablation word of the pipeline mode — bits 8-11 rows per
                                   * producer wave, 12-15 cap on the scan sub-window / 8, 16 `new` rows stored eagerly with row slots
                                   * swapped on acceptance (default for rows without an integral: stale rows are evaluated again),
-                                  * 18 Gram operands from HBM/L2 instead of LDS, 7 XCD-aware block map; bits 0-6 switch stages OFF and
+                                  * 18 Gram operands from HBM/L2 instead of LDS, 19-20 row shares of a SIMD's two producer waves (1 equal, 2 two rows apart), 7 XCD-aware block map; bits 0-6 switch stages OFF and
                                   * give invalid results.  Tools and tests set it, McSAS never does.) */
     const double *replay_stream; /* [n_reps][replay_len] or NULL */
     int64_t  replay_len;

@@ -589,7 +589,16 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         // waited for at the barriers: the rows' global stores drain behind the MFMAs.
         MCSAS_STAMP_DECL(pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0, tg = 0, tb = 0);
         MCSAS_STAMP(pp0);
-        const int W = pa.g.w, nsb = pa.g.sub_per_block, RW = W >> 3, BR = nsb * W;   // RW rows per wave and sub-window
+        // Rows per wave and sub-window: W / 8 on average, but UNEVEN — the four waves that were launched first (one per
+        // SIMD) take one row more, the four that share their SIMDs one row less.  The SIMD arbitrates oldest-first, so
+        // with equal shares the older wave finishes early and the younger one finishes the phase alone, latency-bound
+        // (measured, 3 + 3 rows: 5.2 and 8.6 us); with 4 + 2 both end closer together: 3.92 against 4.03 ms per launch,
+        // 5 + 1: 4.2 ms.  (Tuning bits 19-20: 1 = equal shares, 2 = two rows more / less.)
+        const int W = pa.g.w, nsb = pa.g.sub_per_block, BR = nsb * W;
+        const int rw_even = W >> 3, skew_req = (a.pad0 >> 19) & 3, skew = rw_even < 2 ? 0 : (skew_req == 0 ? 1 : (skew_req == 1 ? 0 : (rw_even >= 3 ? 2 : 1)));
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int RW = wv < 4 ? rw_even + skew : rw_even - skew;                        // my rows per sub-window
+        const int rbase = wv < 4 ? wv * (rw_even + skew) : 4 * (rw_even + skew) + (wv - 4) * (rw_even - skew);   // my first row in a sub-window
         const int buf = t & 1, dstr = qpad + PIPE_DROW_PAD;
         const int64_t w = (int64_t)t - sn.t_init - 1;
         const int64_t sb0 = w * Kb + (int64_t)by * BR;                                 // global step of the block's first row
@@ -600,7 +609,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         double *dbuf = lds + pa.g.drow_off, *gred = lds + pa.g.gram_off + 16;
         const int nmine = nsb * RW;                                                    // my rows (<= 8), lane l <-> my l-th row
         const bool no_gram = a.pad0 & 64;                                              // diagnostic: no Gram blocks (uniform)
-        const int lrow = (lane / RW) * W + wave * RW + (lane % RW);                     // its offset in the block
+        const int lrow = (lane / RW) * W + rbase + (lane % RW);                        // its offset in the block
         const bool lazy = pa.g.lazy_rows;
         PIPE_TLX_MARK(pa, t, 0);
         // ---- lazy rows: the block's stale `old` rows (their last proposal, N steps ago, was accepted: ~6 % of them) are
@@ -617,7 +626,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         const bool old_lane = lazy && l2 >= 0 && l2 < nmine;
         int stale_r = -1;
         if (old_lane) {
-            const int lrow_o = (l2 / RW) * W + wave * RW + (l2 % RW);
+            const int lrow_o = (l2 / RW) * W + rbase + (l2 % RW);
             if (sb0 + lrow_o < max_iter) {
                 const int r = (int)((sb0 + lrow_o) % N);
                 const int v = row_valid[r];
@@ -640,7 +649,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                     double u = 0.5;
                     if (lane < nmine && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
                     const double pv = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
-                    if (!(old_lane && sb0 + ((l2 / RW) * W + wave * RW + (l2 % RW)) < max_iter)) prow[p] = pv;
+                    if (!(old_lane && sb0 + ((l2 / RW) * W + rbase + (l2 % RW)) < max_iter)) prow[p] = pv;
                 }
         }
         Contrib<M> prop;
@@ -690,7 +699,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         for (int ss = 0; ss < nsb; ++ss) {
             for (int jr = 0; jr < RW; ++jr) {
                 const int l = ss * RW + jr, bl = __builtin_amdgcn_readfirstlane(l);
-                const int kl = ss * W + wave * RW + jr, k = by * BR + kl;
+                const int kl = ss * W + rbase + jr, k = by * BR + kl;
                 const Contrib<M> cnew = prop.bcast(bl);
                 const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
                 double d[QPL], nwv[QPL];
@@ -703,7 +712,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                 if (sb0 + kl < max_iter) {                                            // uniform in the wave; rows behind max_iter are masked in the Gram block
                     const auto nrow = cache + (size_t)sslot * qpad + lane;
                     const auto dr = dwin + (size_t)k * qpad + lane;
-                    double *dl = dbuf + (size_t)(wave * RW + jr) * dstr + lane;
+                    double *dl = dbuf + (size_t)(rbase + jr) * dstr + lane;
                     RowEval<M, QPL>::run(cnew, qt, lane, nwv);
                     PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
                     double s1 = 0., s2 = 0., s3 = 0.;

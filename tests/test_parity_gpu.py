@@ -727,11 +727,12 @@ def test_pipeline_tuning_variants_replay_the_reference():
     """The pipeline's alternative layouts, selected by the tuning bits of the diagnostic word and kept for measurements,
     replay the reference's 512 q x 400 contribution chain like the default does: `new` rows stored eagerly and row slots
     swapped on acceptance instead of stale rows evaluated again (bit 16), Gram operands from HBM/L2 instead of the LDS copy
-    of the sub-window (bit 18), other sub-window sizes (bits 12-15) and rows per producer wave (bits 8-11).  (Their Gram
+    of the sub-window (bit 18), other sub-window sizes (bits 12-15), rows per producer wave (bits 8-11) and row shares of the two waves of a SIMD (bits 19-20).  (Their Gram
     blocks are summed in different groupings, so two free-running chains may take different turns at a numerically tied
     step — replacing one negligible sphere by another moves chi² by less than its rounding error — which is why every
     variant is compared with the reference, not with the default layout.)"""
-    for flags in (1 << 16, 1 << 18, (1 << 16) | (1 << 18), 2 << 12, 1 << 12, (1 << 12) | (1 << 16), 8 << 8, 4 << 8, (2 << 8) | (1 << 18), 3 << 8):
+    for flags in (1 << 16, 1 << 18, (1 << 16) | (1 << 18), 2 << 12, 1 << 12, (1 << 12) | (1 << 16), 8 << 8, 4 << 8, (2 << 8) | (1 << 18), 3 << 8,
+                  1 << 19, 2 << 19, (6 << 8) | (2 << 19), (2 << 12) | (6 << 8)):
         g, m, spec, st, ost = traj_setup("g4_sphere_q512_fixed.npz")
         st.exec_mode, st.debug_flags = engine.EXEC_PIPELINE, flags
         res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st, replay=g["stream"][None, :])
