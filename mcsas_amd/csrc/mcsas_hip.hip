@@ -478,9 +478,12 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             // 128 chains, workgroup per chain 2.4 / 2.9 / 3.3e8 at 128 / 192 / 256, wavefront per chain 2.4 / 3.1 / 4.7e8
             // at 384 / 512 / 1024): the pipeline up to 128 chains, one workgroup per chain below 384, one wavefront per
             // chain from there; rows that cost an integral each keep the workgroup's seven producer waves per chain
-            // until the chains alone fill the SIMDs
+            // until the chains alone fill the SIMDs (tools/mode_sweep_heavy.py: cylinders 5.1-5.4e6 steps/s in the pipeline at
+            // any chain count, 3.7 / 5.1 / 5.0e6 per workgroup at 192 / 256 / 512 chains; Kholodenko 3.3-3.5e6 in the
+            // pipeline, 3.2 / 4.3 / 4.3e6 per workgroup, 4.0 / 5.2e6 per wavefront at 1024 / 2048: its row cost varies with
+            // the proposal, which a tick's barrier pays for and independent workgroups average out)
             if (p->n_reps >= (heavy_rows ? 1024 : 384)) mode = MCSAS_EXEC_WAVE;
-            else if (p->n_reps <= 128 && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
+            else if (p->n_reps <= (heavy_rows ? 192 : 128) && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
             else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
             else mode = MCSAS_EXEC_WAVE;
         }
