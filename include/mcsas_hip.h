@@ -22,9 +22,10 @@
 extern "C" {
 #endif
 
-#define MCSAS_ABI_VERSION 2
+#define MCSAS_ABI_VERSION 3
 #define MCSAS_MAX_ACTIVE 4   /* active (fitted) parameters per contribution: columns of rset */
 #define MCSAS_MAX_PARAMS 8   /* full parameter vector of a model */
+#define MCSAS_MAX_DEVICES 16 /* devices one mcsas_hip_analyse call may spread its repetitions over */
 
 /* model_id: which ScatteringModel.formfactor/volume/absVolume/surface set is evaluated.
  * Parameter vector order = the reference's `parameters` tuple of that class. */
@@ -133,6 +134,18 @@ typedef struct mcsas_problem {
     const double *smear_locs;        /* [nq][smear_nk], row-major: where F is evaluated */
     const double *smear_q_offset;    /* [smear_nk] */
     const double *smear_weights;     /* [smear_nk] beam-profile weights */
+
+    /* several GPUs (ABI 3).  The repetition loop of McSAS.analyse (mcsas.py:214-262) is a serial `for nr in
+     * range(numReps)` over chains that share nothing but read-only data; with n_devices > 1 mcsas_hip_analyse runs
+     * contiguous blocks of repetitions on devices[0..n_devices) at the same time (one host thread, one plan and one
+     * stream per device; blocks differ by at most one repetition) and writes every block into the caller's arrays
+     * at its place.  The chain id of a repetition is rep_offset + its index whatever the split, so a repetition's
+     * random stream does not depend on the device count — and neither does its result as long as every block
+     * runs in the same execution mode (set exec_mode; MCSAS_EXEC_AUTO looks at the block's own repetition count).
+     * n_devices = 0 or 1: `device` alone.  A device may be listed more than once.  Plans take `device` only. */
+    int32_t  n_devices;
+    int32_t  devices[MCSAS_MAX_DEVICES];
+    int32_t  reserved2;
 } mcsas_problem;
 
 /* What mcFit returns per repetition (mcsas.py:428-439) gathered the way analyse() stores it
@@ -159,6 +172,9 @@ typedef struct mcsas_result {
  * here: fit[nq] = that intensity, chisq[0] = -1, scaling[0] = 1, background[0] = 0, num_iter[0] = 0 — the
  * result arrays are then used as if n_contrib = n_reps = 1. */
 int mcsas_hip_analyse(const mcsas_problem *problem, mcsas_result *result);
+/* how mcsas_hip_analyse splits n_reps repetitions over n_devices devices: block `index` = repetitions
+ * [*first, *first + *count) (contiguous, in device-list order, sizes differ by at most one; count may be 0) */
+int mcsas_hip_shard(int32_t n_reps, int32_t n_devices, int32_t index, int32_t *first, int32_t *count);
 
 /* ---- resident plan: same work split so that inputs/workspaces live in HBM across runs ------- */
 typedef struct mcsas_plan mcsas_plan;

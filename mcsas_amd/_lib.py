@@ -13,14 +13,15 @@ import numpy as np
 
 MAX_ACTIVE = 4
 MAX_PARAMS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
+MAX_DEVICES = 16
 
 # MCSAS_HIP_LIB selects another build of the SAME library (e.g. the -DMCSAS_STAMPS diagnostic build)
 LIB_PATH = os.environ.get("MCSAS_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmcsas_hip.so")
 
 # every symbol include/mcsas_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = (
-    "mcsas_hip_analyse", "mcsas_hip_plan_create", "mcsas_hip_plan_launch", "mcsas_hip_plan_fetch",
+    "mcsas_hip_analyse", "mcsas_hip_shard", "mcsas_hip_plan_create", "mcsas_hip_plan_launch", "mcsas_hip_plan_fetch",
     "mcsas_hip_plan_last_ms", "mcsas_hip_plan_total_steps", "mcsas_hip_plan_reseed", "mcsas_hip_plan_info",
     "mcsas_hip_plan_destroy", "mcsas_hip_model_calc", "mcsas_hip_bgfit", "mcsas_hip_observability",
     "mcsas_hip_histogram_prep", "mcsas_hip_prepare_uncertainty", "mcsas_hip_rebin",
@@ -57,6 +58,7 @@ class Problem(C.Structure):
         ("cache_intensities", C.c_int32), ("exec_mode", C.c_int32),
         ("smear_nk", C.c_int32), ("reserved1", C.c_int32),
         ("smear_locs", _dp), ("smear_q_offset", _dp), ("smear_weights", _dp),
+        ("n_devices", C.c_int32), ("devices", C.c_int32 * MAX_DEVICES), ("reserved2", C.c_int32),
     ]
 
 
@@ -97,6 +99,7 @@ def load():
     lib.mcsas_hip_last_error.restype = C.c_char_p
     lib.mcsas_hip_device_count.restype = C.c_int
     lib.mcsas_hip_analyse.argtypes = [C.POINTER(Problem), C.POINTER(Result)]
+    lib.mcsas_hip_shard.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p]
     lib.mcsas_hip_plan_create.argtypes = [C.POINTER(Problem), C.POINTER(C.c_void_p)]
     lib.mcsas_hip_plan_launch.argtypes = [C.c_void_p, C.c_void_p]
     lib.mcsas_hip_plan_fetch.argtypes = [C.c_void_p, C.POINTER(Result)]

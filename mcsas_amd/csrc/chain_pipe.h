@@ -26,6 +26,7 @@
 // tick parity, so a producer never reads a record that a concurrently running scan is writing.
 #pragma once
 #include "chain_common.h"
+#include <type_traits>
 
 namespace mcsas {
 
@@ -90,8 +91,8 @@ struct PipeGeom {
     int32_t sub_per_block;        // scan sub-windows per producer block (8 * rows_per_wave / w)
     int32_t lazy_rows;            // no `new` rows are stored: an accepted step marks its contribution's cached row stale and the producer that
                                   // next needs it as `old` evaluates it again from the parameter set (rows without an integral only)
-    int32_t gram_lds;             // producer: the sub-window's d rows are also kept in LDS and the Gram MFMAs read them from there
-    int32_t drow_off;             // producer LDS: offset (doubles) of those rows, row stride qpad + PIPE_DROW_PAD
+    int32_t overlap;              // producer: rows without an integral — the Gram MFMAs of sub-window s are issued between the rows of s + 1
+    int32_t pad_g;
     uint64_t prod_lds, scan_lds;
 };
 
@@ -140,7 +141,7 @@ __device__ __forceinline__ void store_snap(PipeSnap *p, const PipeSnap &s) {
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
 constexpr int PIPE_WAVES = PIPE_BLOCK / 64;
 constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;
-constexpr int PIPE_DROW_PAD = 8;         // LDS d rows: stride qpad + 8 doubles, so that the 64 16-byte operands of one Gram load hit 64 different bank groups
+constexpr int PIPE_GRAM_NT_MAX = 3;          // overlapped producer: tiles per sub-window — W <= 32 (two 16-row groups: 3 tiles) or 24 packed (2)
 constexpr int PIPE_MAX_ROW_DOUBLES = 32;   // scan block: doubles per lane held in row registers (rows per wave and sub-window x q per lane)   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
@@ -156,6 +157,20 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     // the first one whose window is within 15 % of the largest wins.
     // Rows that cost a numerical integration each (cylinders, ellipsoids, worm-like chains): one row per
     // producer wave, so that a window is R*Kb waves for the 1024 SIMDs instead of R*Kb/8.
+    // scan sub-window for `r` rows per producer wave: the largest multiple of 8 that divides the producer block's rows and
+    // whose d rows fit the scan block's LDS row buffer (the accepted rows are applied to ft from there, not from HBM).
+    // Rows without an integral run the overlapped producer (Gram of sub-window s between the rows of s + 1), whose tile
+    // schemes cover W <= 32.
+    const bool overlap = !heavy_rows && !gram_global_req;
+    auto pick_w = [&](int r) {
+        int w = 8;
+        for (int ws = 8; ws <= 8 * r && ws <= (overlap ? 32 : 64); ws += 8) {
+            const int rps = ws / 8;
+            if (rps == 5 || rps == 7 || rps * qpl > PIPE_MAX_ROW_DOUBLES) continue;   // the kernels instantiate 1, 2, 3, 4, 6, 8 rows per wave
+            if ((8 * r) % ws == 0 && sizeof(double) * (size_t)ws * qpad <= 96 * 1024 && (sub_req == 0 || ws <= 8 * sub_req)) w = ws;
+        }
+        return w;
+    };
     int rpw = 0, by = 0;
     if (rows_per_wave_req >= 1 && rows_per_wave_req <= 8) rpw = rows_per_wave_req;
     else if (heavy_rows) rpw = 1;
@@ -188,49 +203,42 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
             if (kbs[c] > best_kb) best_kb = kbs[c];
         }
         if (best_kb == 0) return 1;
+        // default: the first candidate whose window is within 15 % of the largest
+        int rpw_d = 0, by_d = 0;
+        for (int c = 0; c < 6 && !rpw_d; ++c)
+            if (kbs[c] > 0 && 20 * kbs[c] >= 17 * best_kb) { rpw_d = order[c]; by_d = kbs[c] / (8 * rpw_d); }
         // Few chains: more, smaller producer blocks per chain shorten the producers' critical path (start-up + rows
         // per wave + Gram) down to where the scan block becomes the longer one — as long as every block still gets a
         // CU of its own.  Measured at 512 q x 400 (tools/sweep_rpw.sh): 3 rows per wave 3.1-3.3 ms per launch up to 28
-        // chains, 4 rows 3.3-3.6 ms up to 36, 6 rows 3.8-4.0 ms up to 51.
+        // chains, 6 rows 3.8-4.0 ms up to 51.  Only candidates with the SAME window and the same scan sub-window as
+        // the default qualify: a chain's decisions depend on both (where the running sums are re-derived from ft, which
+        // pairs of steps go through the Gram block), and a repetition must come out the same whether it runs beside 6
+        // others (one of eight GPUs) or beside 49.
         if (n_chains > 0 && n_cus > 0) {
             static const int small_first[6] = {3, 4, 6, 8, 2, 1};
             for (int c = 0; c < 6 && !rpw; ++c) {
                 const int r = small_first[c];
                 int b = (2 * 8 * r > n_contrib) ? 0 : n_contrib / (2 * 8 * r);
                 if (b * 8 * r > 256) b = 256 / (8 * r);
-                if (b > 0 && 20 * (b * 8 * r) >= 17 * best_kb && n_chains * (b + 1) <= n_cus) { rpw = r; by = b; }
+                if (b > 0 && b * 8 * r == by_d * 8 * rpw_d && pick_w(r) == pick_w(rpw_d) && n_chains * (b + 1) <= n_cus) { rpw = r; by = b; }
             }
         }
-        for (int c = 0; c < 6 && !rpw; ++c)                   // a window within 15 % of the largest is as good
-            if (kbs[c] > 0 && 20 * kbs[c] >= 17 * best_kb) { rpw = order[c]; by = kbs[c] / (8 * rpw); }
+        if (!rpw) { rpw = rpw_d; by = by_d; }
     }
     g->kb = by * 8 * rpw; g->qpl = qpl;
-    // scan sub-window: the largest multiple of 8 that divides the producer block's rows and whose d rows fit the
-    // scan block's LDS row buffer (the accepted rows are applied to ft from there, not from HBM)
-    g->w = 8;
-    for (int ws = 8; ws <= 8 * rpw && ws <= 64; ws += 8) {
-        const int rps = ws / 8;
-        if (rps == 5 || rps == 7 || rps * qpl > PIPE_MAX_ROW_DOUBLES) continue;   // the kernels instantiate 1, 2, 3, 4, 6, 8 rows per wave
-        if ((8 * rpw) % ws == 0 && sizeof(double) * (size_t)ws * qpad <= 96 * 1024 && (sub_req == 0 || ws <= 8 * sub_req)) g->w = ws;
-    }
+    g->w = pick_w(rpw);
     g->sub_per_block = 8 * rpw / g->w;
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
     g->gram_off = 4 * qpad + tab_doubles;
     {
-        const int tg = (g->w + 15) / 16, nt = tg * (tg + 1) / 2;
-        const size_t red = (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256;
-        (void)nt;
-        g->prod_lds = sizeof(double) * ((size_t)g->gram_off + 16 + red);    // 16 doubles: hand-off counters
-        // Rows without an integral: the Gram phase is a third of the producer's tick; with the sub-window's d rows parked
-        // in LDS on their way to HBM it is MFMA-bound instead of waiting for an L2 round trip per sub-window.
-        g->gram_lds = 0; g->drow_off = 0;
-        const size_t with_rows = g->prod_lds + sizeof(double) * (size_t)g->w * (qpad + PIPE_DROW_PAD);
-        if (!heavy_rows && !gram_global_req && with_rows <= 160 * 1024) {
-            g->gram_lds = 1; g->drow_off = g->gram_off + 16 + (int)red; g->prod_lds = with_rows;
-        }
+        // reduction buffer of the Gram tiles: [8 waves][tiles][256]; the overlapped producer keeps two of them (the block of
+        // sub-window s is summed while the partial tiles of s + 1 are being parked)
+        const size_t red = overlap ? (size_t)2 * PIPE_WAVES * PIPE_GRAM_NT_MAX * 256 : (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256;
+        g->prod_lds = sizeof(double) * ((size_t)g->gram_off + 16 + red);    // 16 doubles: counters
+        g->overlap = overlap ? 1 : 0; g->pad_g = 0;
         // ... and no `new` rows go to HBM either (4 KB per step at Q = 512, a fifth of the tick's memory traffic): see lazy_rows
-        g->lazy_rows = (g->gram_lds && !eager_req) ? 1 : 0;
+        g->lazy_rows = (overlap && !eager_req) ? 1 : 0;
     }
     g->scan_waves = PIPE_WAVES;
     // scan block LDS: the sub-window's d rows, two Gram blocks (double buffer), ft and w*ft, the window's scalars, h of
@@ -401,38 +409,51 @@ __device__ __forceinline__ void pipe_prod_gram(const MCSAS_GLOBAL double *drows,
 }
 
 
-// The same Gram block with the operands read from the LDS copy of the sub-window's d rows (row stride dstr).
+// ---- the Gram block in UNITS, for producers that evaluate the next sub-window's rows at the same time ----------------
+// Rows without an integral: the Gram MFMAs of sub-window s are issued BETWEEN the rows of sub-window s + 1 (the matrix
+// pipe runs beside the vector pipe: while one wave of a SIMD is inside a run of MFMAs its partner has the vector issue
+// slots to itself), so a wave's share of a block — its q slice of 8 QPL points, every row — is cut into QPL units of 8 q
+// (two MFMA k-steps per tile) that are done a few at a time.  Operands come from the window buffer the rows were just
+// stored to (HBM/L2; same CU, same L1: visible to the whole workgroup once the storing waves have waited for their
+// stores and passed a barrier).  The accumulators stay in registers between the calls.
 // PACK (W = 24, three 8-row groups g0 g1 g2): the six upper-triangular 8x8 blocks fit TWO 16x16 tiles instead of the
 // three of the 16-row grouping — tile 0 = rows [g0 g1] x columns [g1 g2] (blocks 01 02 11 12), tile 1 = rows and
 // columns [g0 g2] (blocks 00 22; its 02 is a duplicate and not stored): a third fewer MFMAs.
+
 template <int QPL, int T, bool PACK>
-__device__ __forceinline__ void pipe_gram_mfma_lds(const double *drows, int dstr, int nvalid, const double *lw, int gw,
-                                                   v4f64 (&acc)[PACK ? 2 : T * (T + 1) / 2]) {
+__device__ __forceinline__ void pipe_gram_units(const MCSAS_GLOBAL double *drows, int qpad, int nvalid, const double *lw, int gw,
+                                                int u0, int u1, v4f64 (&acc)[PIPE_GRAM_NT_MAX]) {
+    static_assert(T <= 2, "at most two 16-row groups per sub-window");
     const int lane = threadIdx.x & 63;
     const int m = lane & 15, kk = lane >> 4;
-    constexpr int NT = PACK ? 2 : T * (T + 1) / 2;
-    constexpr int NL = PACK ? 3 : T;                          // row operands per lane and step-pair
-    constexpr int SLICE = 64 * QPL / PIPE_WAVES;
+    constexpr int NL = PACK ? 3 : T;                          // row operands per lane and unit
+    constexpr int SLICE = 64 * QPL / PIPE_WAVES;              // q per wave = 8 * (units per wave)
     static_assert(SLICE >= 8, "too many waves for this q count");
     const int qs = gw * SLICE + kk * 2;
+    if (u0 == 0) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0., 0., 0., 0.};
-    const double *rowp[NL];
+        for (int i = 0; i < PIPE_GRAM_NT_MAX; ++i) acc[i] = (v4f64){0., 0., 0., 0.};
+    }
+    const MCSAS_GLOBAL double *rowp[NL];
     bool rowok[NL];
 #pragma unroll
     for (int gi = 0; gi < NL; ++gi) {
         const int rr = PACK ? (gi == 0 ? m : gi == 1 ? 8 + m : (m < 8 ? m : m + 8)) : 16 * gi + m;
         rowok[gi] = rr < nvalid;
-        rowp[gi] = drows + (size_t)(rowok[gi] ? rr : 0) * dstr + qs;
+        rowp[gi] = drows + (size_t)(rowok[gi] ? rr : 0) * qpad + qs;
     }
+    v2f64 cur[NL], nxt[NL];
 #pragma unroll
-    for (int sp = 0; sp < SLICE / 8; ++sp) {
+    for (int gi = 0; gi < NL; ++gi) cur[gi] = *(const MCSAS_GLOBAL v2f64 *)(rowp[gi] + 8 * u0);
+    for (int u = u0; u < u1; ++u) {
+        const int un = u + 1 < u1 ? u + 1 : u;                // (the last unit is requested twice: no load under a condition)
+#pragma unroll
+        for (int gi = 0; gi < NL; ++gi) nxt[gi] = *(const MCSAS_GLOBAL v2f64 *)(rowp[gi] + 8 * un);
+        const v2f64 wv = *reinterpret_cast<const v2f64 *>(lw + qs + 8 * u);
         v2f64 av[NL], bv[NL];
-        const v2f64 wv = *reinterpret_cast<const v2f64 *>(lw + qs + 8 * sp);
 #pragma unroll
         for (int gi = 0; gi < NL; ++gi) {
-            const v2f64 x = *reinterpret_cast<const v2f64 *>(rowp[gi] + 8 * sp);
-            av[gi] = rowok[gi] ? x : (v2f64){0., 0.};
+            av[gi] = rowok[gi] ? cur[gi] : (v2f64){0., 0.};
             bv[gi] = av[gi] * wv;
         }
         if constexpr (PACK) {
@@ -445,63 +466,135 @@ __device__ __forceinline__ void pipe_gram_mfma_lds(const double *drows, int dstr
 #pragma unroll
             for (int gi = 0; gi < T; ++gi)
 #pragma unroll
-                for (int gj = gi; gj < T; ++gj) {
-                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].x, bv[gj].x, acc[ti], 0, 0, 0);
-                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].y, bv[gj].y, acc[ti], 0, 0, 0);
-                    ++ti;
-                }
+                for (int gj = gi; gj < T; ++gj) { acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].x, bv[gj].x, acc[ti], 0, 0, 0); ++ti; }
+            ti = 0;
+#pragma unroll
+            for (int gi = 0; gi < T; ++gi)
+#pragma unroll
+                for (int gj = gi; gj < T; ++gj) { acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].y, bv[gj].y, acc[ti], 0, 0, 0); ++ti; }
         }
+#pragma unroll
+        for (int gi = 0; gi < NL; ++gi) cur[gi] = nxt[gi];
     }
 }
 
-// element idx of packed tile tsel -> (row, column) of the 24-step sub-window, or skipped
-__device__ __forceinline__ void pipe_gram_store_pack(int tsel, int idx, double sum, MCSAS_GLOBAL double *gout) {
-    const int i = 4 * (idx >> 6) + ((idx & 63) >> 4), j = idx & 15;
-    if (tsel == 0) gout[(size_t)i * 24 + 8 + j] = sum;
-    else if ((i < 8) == (j < 8)) gout[(size_t)(i < 8 ? i : i + 8) * 24 + (j < 8 ? j : j + 8)] = sum;
-}
-
+// The same units with the operand loads and the MFMAs as two calls, so that a row evaluation fits between them: the loads
+// of up to UCAP = 12 / NL units are in flight while the row is computed, the MFMAs run on landed operands.
+constexpr int PIPE_GRAM_PREF = 12;                             // 16-byte operand registers per lane held across a row evaluation
+template <int T, bool PACK> struct PipeGramScheme {
+    static constexpr int NL = PACK ? 3 : T;
+    static constexpr int UCAP = PIPE_GRAM_PREF / NL;
+};
 template <int QPL, int T, bool PACK>
-__device__ __forceinline__ void pipe_prod_gram_lds_t(const double *drows, int dstr, int W, int nvalid, const double *lw,
-                                                     double *gred, MCSAS_GLOBAL double *gout) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NT = PACK ? 2 : T * (T + 1) / 2;
-    v4f64 acc[NT];
-    pipe_gram_mfma_lds<QPL, T, PACK>(drows, dstr, nvalid, lw, wave, acc);
-    constexpr int TPR = PIPE_GRAM_TILES_PER_ROUND;
+__device__ __forceinline__ void pipe_gram_fetch(const MCSAS_GLOBAL double *drows, int qpad, int nvalid, int gw, int u0, int n,
+                                                v2f64 (&G)[PIPE_GRAM_PREF]) {
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kk = lane >> 4;
+    constexpr int NL = PipeGramScheme<T, PACK>::NL, UCAP = PipeGramScheme<T, PACK>::UCAP;
+    constexpr int SLICE = 64 * QPL / PIPE_WAVES;
+    const int qs = gw * SLICE + kk * 2;
 #pragma unroll
-    for (int r0 = 0; r0 < NT; r0 += TPR) {
+    for (int gi = 0; gi < NL; ++gi) {
+        const int rr = PACK ? (gi == 0 ? m : gi == 1 ? 8 + m : (m < 8 ? m : m + 8)) : 16 * gi + m;
+        const MCSAS_GLOBAL double *rowp = drows + (size_t)(rr < nvalid ? rr : 0) * qpad + qs;
 #pragma unroll
-        for (int u = 0; u < TPR; ++u)
-            if (r0 + u < NT) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) gred[((size_t)(wave * TPR + u) * 4 + r) * 64 + lane] = acc[r0 + u < NT ? r0 + u : 0][r];
-            }
-        PIPE_LDS_BARRIER();
-        {
-            const int u = tid >> 8, idx = tid & 255;
-            const int tsel = r0 + u;
-            if (tsel < NT) {
-                double sum = 0.;
-#pragma unroll
-                for (int v = 0; v < PIPE_WAVES; ++v) sum += gred[(size_t)(v * TPR + u) * 256 + idx];
-                if constexpr (PACK) pipe_gram_store_pack(tsel, idx, sum, gout);
-                else pipe_gram_store<T>(tsel, idx, sum, W, gout);
-            }
+        for (int i = 0; i < UCAP; ++i) {
+            const int u = u0 + (i < n ? i : n - 1);           // (past the chunk: its last unit again — no load under a condition)
+            G[i * NL + gi] = *(const MCSAS_GLOBAL v2f64 *)(rowp + 8 * u);
         }
-        if (r0 + TPR < NT) PIPE_LDS_BARRIER();
     }
 }
+template <int QPL, int T, bool PACK>
+__device__ __forceinline__ void pipe_gram_consume(const v2f64 (&G)[PIPE_GRAM_PREF], int nvalid, const double *lw, int gw, int u0, int n,
+                                                  v4f64 (&acc)[PIPE_GRAM_NT_MAX]) {
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kk = lane >> 4;
+    constexpr int NL = PipeGramScheme<T, PACK>::NL, UCAP = PipeGramScheme<T, PACK>::UCAP;
+    constexpr int SLICE = 64 * QPL / PIPE_WAVES;
+    const int qs = gw * SLICE + kk * 2;
+    if (u0 == 0) {
+#pragma unroll
+        for (int i = 0; i < PIPE_GRAM_NT_MAX; ++i) acc[i] = (v4f64){0., 0., 0., 0.};
+    }
+    bool rowok[NL];
+#pragma unroll
+    for (int gi = 0; gi < NL; ++gi) {
+        const int rr = PACK ? (gi == 0 ? m : gi == 1 ? 8 + m : (m < 8 ? m : m + 8)) : 16 * gi + m;
+        rowok[gi] = rr < nvalid;
+    }
+#pragma unroll
+    for (int i = 0; i < UCAP; ++i)
+        if (i < n) {                                          // uniform
+            const v2f64 wv = *reinterpret_cast<const v2f64 *>(lw + qs + 8 * (u0 + i));
+            v2f64 av[NL], bv[NL];
+#pragma unroll
+            for (int gi = 0; gi < NL; ++gi) {
+                av[gi] = rowok[gi] ? G[i * NL + gi] : (v2f64){0., 0.};
+                bv[gi] = av[gi] * wv;
+            }
+            if constexpr (PACK) {
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0].x, bv[1].x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2].x, bv[2].x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0].y, bv[1].y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2].y, bv[2].y, acc[1], 0, 0, 0);
+            } else {
+                int ti = 0;
+#pragma unroll
+                for (int gi = 0; gi < T; ++gi)
+#pragma unroll
+                    for (int gj = gi; gj < T; ++gj) { acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].x, bv[gj].x, acc[ti], 0, 0, 0); ++ti; }
+                ti = 0;
+#pragma unroll
+                for (int gi = 0; gi < T; ++gi)
+#pragma unroll
+                    for (int gj = gi; gj < T; ++gj) { acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].y, bv[gj].y, acc[ti], 0, 0, 0); ++ti; }
+            }
+        }
+}
 
+// the launch-uniform choice of the tile scheme (W <= 32 by pipe_geometry for these rows)
 template <int QPL>
-__device__ __forceinline__ void pipe_prod_gram_lds(const double *drows, int dstr, int W, int nvalid, const double *lw,
-                                                   double *gred, MCSAS_GLOBAL double *gout) {
-    if (W == 24) { pipe_prod_gram_lds_t<QPL, 2, true>(drows, dstr, W, nvalid, lw, gred, gout); return; }
-    switch ((W + 15) >> 4) {                                   // uniform for the launch
-        case 1: pipe_prod_gram_lds_t<QPL, 1, false>(drows, dstr, W, nvalid, lw, gred, gout); break;
-        case 2: pipe_prod_gram_lds_t<QPL, 2, false>(drows, dstr, W, nvalid, lw, gred, gout); break;
-        case 3: pipe_prod_gram_lds_t<QPL, 3, false>(drows, dstr, W, nvalid, lw, gred, gout); break;
-        default: pipe_prod_gram_lds_t<QPL, 4, false>(drows, dstr, W, nvalid, lw, gred, gout); break;
+__device__ __forceinline__ void pipe_gram_units_w(int W, const MCSAS_GLOBAL double *drows, int qpad, int nvalid, const double *lw, int gw,
+                                                  int u0, int u1, v4f64 (&acc)[PIPE_GRAM_NT_MAX]) {
+    if (W == 24) pipe_gram_units<QPL, 2, true>(drows, qpad, nvalid, lw, gw, u0, u1, acc);
+    else if (W <= 16) pipe_gram_units<QPL, 1, false>(drows, qpad, nvalid, lw, gw, u0, u1, acc);
+    else pipe_gram_units<QPL, 2, false>(drows, qpad, nvalid, lw, gw, u0, u1, acc);
+}
+__device__ __forceinline__ int pipe_gram_tiles(int W) { return W == 24 ? 2 : (W <= 16 ? 1 : 3); }
+
+// a wave's partial tiles -> its slots of the reduction buffer gred[wave][tile][256]
+__device__ __forceinline__ void pipe_gram_park(const v4f64 (&acc)[PIPE_GRAM_NT_MAX], int nt, double *gred, int wave, int lane) {
+#pragma unroll
+    for (int ti = 0; ti < PIPE_GRAM_NT_MAX; ++ti)
+        if (ti < nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gred[((size_t)(wave * PIPE_GRAM_NT_MAX + ti) * 4 + r) * 64 + lane] = acc[ti][r];
+        }
+}
+
+// all threads: the eight waves' partial tiles summed in wave order (deterministic), Gram block to gout[a][k] (a, k < W), and
+// its diagonal — g_k = sum_q w d_k^2, the third of a step's ft-independent sums — to scal_sub[k][2]
+__device__ __forceinline__ void pipe_gram_sum_store(int W, const double *gred, MCSAS_GLOBAL double *gout, MCSAS_GLOBAL double *scal_sub) {
+    const int tid = threadIdx.x;
+    const int nt = pipe_gram_tiles(W);
+    for (int e = tid; e < nt * 256; e += PIPE_BLOCK) {
+        const int ti = e >> 8, idx = e & 255;
+        double sum = 0.;
+#pragma unroll
+        for (int v = 0; v < PIPE_WAVES; ++v) sum += gred[(size_t)(v * PIPE_GRAM_NT_MAX + ti) * 256 + idx];
+        const int i = 4 * (idx >> 6) + ((idx & 63) >> 4), j = idx & 15;   // result register r of lane l holds D[4 r + l / 16][l % 16]
+        int ar = -1, kc = -1;
+        if (W == 24) {
+            if (ti == 0) { ar = i; kc = 8 + j; }
+            else if ((i < 8) == (j < 8)) { ar = i < 8 ? i : i + 8; kc = j < 8 ? j : j + 8; }
+        } else {
+            const int tgi = ti == 2 ? 1 : 0, tgj = ti == 0 ? 0 : 1;     // tiles (0,0), (0,1), (1,1)
+            ar = 16 * tgi + i; kc = 16 * tgj + j;
+        }
+        if (ar >= 0 && ar < W && kc < W) {
+            gout[(size_t)ar * W + kc] = sum;
+            if (ar == kc) scal_sub[ar * 4 + 2] = sum;
+        }
     }
 }
 
@@ -583,30 +676,33 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     }
 
     if (a.pad0 & 16) return;                                  // diagnostic: no window rows
-    if constexpr (pipe_light_model(M)) if (pa.g.gram_lds) {        // (rows with an integral never take this path: not instantiated for them)
-        // ---- sub-window by sub-window: every wave evaluates its W/8 rows of the sub-window (d also into the LDS row
-        // buffer), barrier, the eight waves take the Gram block from LDS, next sub-window.  Only the LDS traffic is
-        // waited for at the barriers: the rows' global stores drain behind the MFMAs.
-        MCSAS_STAMP_DECL(pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0, tg = 0, tb = 0);
-        MCSAS_STAMP(pp0);
-        // Rows per wave and sub-window: W / 8 on average, but UNEVEN — the four waves that were launched first (one per
-        // SIMD) take one row more, the four that share their SIMDs one row less.  The SIMD arbitrates oldest-first, so
-        // with equal shares the older wave finishes early and the younger one finishes the phase alone, latency-bound
-        // (measured, 3 + 3 rows: 5.2 and 8.6 us); with 4 + 2 both end closer together: 3.92 against 4.03 ms per launch,
-        // 5 + 1: 4.2 ms.  (Tuning bits 19-20: 1 = equal shares, 2 = two rows more / less.)
+    if constexpr (pipe_light_model(M)) if (pa.g.overlap) {         // (rows with an integral never take this path: not instantiated for them)
+        // ---- overlapped producer.  The block's rows are nsb sub-windows of W; phase ss = the rows of sub-window ss, every
+        // wave its share, d = new - old straight to the window buffer.  The Gram block of sub-window ss - 1 is worked off
+        // in units BETWEEN the rows of phase ss (matrix pipe beside the vector pipe: while one wave of a SIMD is inside a run
+        // of MFMAs its partner has the vector issue slots to itself), its operands read back from the window buffer.
+        // One barrier per phase, and it waits for no memory: a wave passes B(ss - 1) — "the rows of ss - 1 are visible to the
+        // workgroup" — behind its FIRST row of phase ss, after a counted wait that covers exactly its stores of phase
+        // ss - 1 (the counter is in order: everything older than that row's own stores has completed by then).  The partial
+        // tiles of a block are parked in LDS when a wave has done its last unit and summed by all threads behind the next
+        // barrier (two reduction buffers, by parity).  Only the last sub-window's Gram block runs with nothing beside it.
         const int W = pa.g.w, nsb = pa.g.sub_per_block, BR = nsb * W;
-        const int rw_even = W >> 3, skew_req = (a.pad0 >> 19) & 3, skew = rw_even < 2 ? 0 : (skew_req == 0 ? 1 : (skew_req == 1 ? 0 : (rw_even >= 3 ? 2 : 1)));
+        // Rows per wave and sub-window: W / 8 on average; tuning bits 19-20 shift rows from the four waves that share
+        // their SIMDs with an older wave (4-7) to the older ones (0-3): 0 = equal shares, 1 / 2 = one / two rows.
+        const int rw_even = W >> 3, skew_req = (a.pad0 >> 19) & 3, skew = skew_req < rw_even ? skew_req : rw_even - 1;
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const int RW = wv < 4 ? rw_even + skew : rw_even - skew;                        // my rows per sub-window
         const int rbase = wv < 4 ? wv * (rw_even + skew) : 4 * (rw_even + skew) + (wv - 4) * (rw_even - skew);   // my first row in a sub-window
-        const int buf = t & 1, dstr = qpad + PIPE_DROW_PAD;
+        const int buf = t & 1;
         const int64_t w = (int64_t)t - sn.t_init - 1;
         const int64_t sb0 = w * Kb + (int64_t)by * BR;                                 // global step of the block's first row
         auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
         auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
         auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
         auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
-        double *dbuf = lds + pa.g.drow_off, *gred = lds + pa.g.gram_off + 16;
+        auto gwin = glb(pa.gwin) + ((size_t)rep * 2 + buf) * Kb * W;
+        double *gred = lds + pa.g.gram_off + 16;                                       // [2][8 waves][PIPE_GRAM_NT_MAX][256]
+        constexpr size_t GRED = (size_t)PIPE_WAVES * PIPE_GRAM_NT_MAX * 256;
         const int nmine = nsb * RW;                                                    // my rows (<= 8), lane l <-> my l-th row
         const bool no_gram = a.pad0 & 64;                                              // diagnostic: no Gram blocks (uniform)
         const int lrow = (lane / RW) * W + rbase + (lane % RW);                        // its offset in the block
@@ -684,90 +780,130 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                 if (tid == 0) row_valid[r] = 1;
             }
             if (nst) __syncthreads();                             // the refreshed rows have landed before the row loop loads them (uniform)
+            else PIPE_LDS_BARRIER();                              // (the stale list shares the reduction buffer: read by all before it is reused)
         }
         PIPE_TLX_MARK(pa, t, 2);
-        // (requesting this row speculatively before the stale rows are known, and reading it again past the vector cache
-        // when it turns out stale, was measured: no gain)
-        double ocur[QPL], onext[QPL];
-        {
-            const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
-#pragma unroll
-            for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
-        }
-        PIPE_PIN_ROW(ocur);                                       // (a pending load carried into the loop would be waited for at its head, every iteration)
         PIPE_TLX_MARK(pa, t, 3);
-        for (int ss = 0; ss < nsb; ++ss) {
-            for (int jr = 0; jr < RW; ++jr) {
-                const int l = ss * RW + jr, bl = __builtin_amdgcn_readfirstlane(l);
-                const int kl = ss * W + rbase + jr, k = by * BR + kl;
-                const Contrib<M> cnew = prop.bcast(bl);
-                const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
-                double d[QPL], nwv[QPL];
-                {
-                    const int bn = __builtin_amdgcn_readfirstlane(l + 1 < nmine ? l + 1 : l);
-                    const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bn) * qpad + lane;
+        // proposals and replay-overflow flags of all my rows: one store per wave (lane l <-> my l-th row)
+        if (lane < nmine) {
+            const int k = by * BR + lrow;
 #pragma unroll
-                    for (int j = 0; j < QPL; ++j) onext[j] = orow[WAVE * j];
-                }
-                if (sb0 + kl < max_iter) {                                            // uniform in the wave; rows behind max_iter are masked in the Gram block
+            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) if (p < P) pval[k * MCSAS_MAX_ACTIVE + p] = prow[p];
+            povf[k] = pov;
+        }
+        const int ntiles = pipe_gram_tiles(W);
+        constexpr int UN = QPL;                                   // Gram units (8 q each) of my q slice
+        auto nvalid_of = [&](int ss) {
+            const int64_t left = max_iter - (w * Kb + (int64_t)(by * nsb + ss) * W);
+            return left >= W ? W : (left > 0 ? (int)left : 0);
+        };
+        // the tile scheme is uniform for the launch; everything below is compiled once per scheme
+        auto rows_and_gram = [&](auto scheme_t, auto scheme_pack) {
+            constexpr int T = decltype(scheme_t)::value;
+            constexpr bool PACK = decltype(scheme_pack)::value;
+            constexpr int UCAP = PipeGramScheme<T, PACK>::UCAP;
+            v4f64 gacc[PIPE_GRAM_NT_MAX];
+            v2f64 G[PIPE_GRAM_PREF];
+            for (int ss = 0; ss < nsb; ++ss) {
+                const int nv_prev = ss > 0 ? nvalid_of(ss - 1) : 0;
+                const bool gram_live = ss > 0 && !no_gram && nv_prev > 0;             // uniform in the block
+                const auto dprev = dwin + (size_t)(by * BR + (ss > 0 ? ss - 1 : 0) * W) * qpad;
+                for (int jr = 0; jr < RW; ++jr) {
+                    const int l = ss * RW + jr, bl = __builtin_amdgcn_readfirstlane(l);
+                    const int kl = ss * W + rbase + jr, k = by * BR + kl;
+                    const Contrib<M> cnew = prop.bcast(bl);
+                    const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
+                    // the `old` row of THIS step is requested here and used behind the row evaluation, which is longer than the
+                    // round trip (a row of lookahead would hold another QPL doubles per lane across the evaluation, beside the
+                    // Gram operands and accumulators)
+                    double d[QPL], nwv[QPL], ocur[QPL];
+                    {
+                        const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bl) * qpad + lane;
+#pragma unroll
+                        for (int j = 0; j < QPL; ++j) ocur[j] = orow[WAVE * j];
+                    }
+                    // my units of block ss - 1 that go with this row (none with the first row of a phase: B(ss - 1) comes
+                    // behind it): their operands are requested now and land while the row is evaluated
+                    const int u0 = (RW > 1 && jr > 0) ? UN * (jr - 1) / (RW - 1) : 0, u1 = (RW > 1 && jr > 0) ? UN * jr / (RW - 1) : 0;
+                    const int npre = u1 - u0 < UCAP ? u1 - u0 : UCAP;
+                    const bool chunk = gram_live && npre > 0;                        // uniform in the wave
+                    if (chunk) pipe_gram_fetch<QPL, T, PACK>(dprev, qpad, nv_prev, wv, u0, npre, G);
+                    else {
+#pragma unroll
+                        for (int i = 0; i < PIPE_GRAM_PREF; ++i) asm volatile("" : "=v"(G[i]));   // (defined on both paths: no copy at the join)
+                    }
+                    // (a row behind max_iter — the last window of a run only — is evaluated like any other: its proposal is the
+                    // generators' midpoint, its stores land in slots nobody reads, the Gram block masks it; no branch around the
+                    // row means no join at which the compiler would wait for this row's stores)
                     const auto nrow = cache + (size_t)sslot * qpad + lane;
                     const auto dr = dwin + (size_t)k * qpad + lane;
-                    double *dl = dbuf + (size_t)(rbase + jr) * dstr + lane;
                     RowEval<M, QPL>::run(cnew, qt, lane, nwv);
-                    PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
-                    double s1 = 0., s2 = 0., s3 = 0.;
+                    PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(nwv);                        // the `old` row has landed before the first store is issued
+                    if (chunk) {
+                        pipe_gram_consume<QPL, T, PACK>(G, nv_prev, lw, wv, u0, npre, gacc);
+                        if (u0 + npre < u1) pipe_gram_units<QPL, T, PACK>(dprev, qpad, nv_prev, lw, wv, u0 + npre, u1, gacc);
+                        if (u1 == UN) pipe_gram_park(gacc, ntiles, gred + (size_t)((ss - 1) & 1) * GRED, wv, lane);
+                    }
+                    double s1 = 0., s2 = 0.;
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {
                         const int iq = lane + WAVE * j;
                         if (!lazy) nrow[WAVE * j] = nwv[j];
                         d[j] = nwv[j] - ocur[j];
                         dr[WAVE * j] = d[j];
-                        dl[WAVE * j] = d[j];
-                        const double wd = lw[iq] * d[j];
-                        s1 += wd; s2 += lwI[iq] * d[j]; s3 += wd * d[j];
+                        s1 = fma(lw[iq], d[j], s1); s2 = fma(lwI[iq], d[j], s2);
                     }
-                    wave_sum3(s1, s2, s3);
-                    if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
-#pragma unroll
-                    for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
-                        if (p < P) {
-                            const double v = readlane_f64(prow[p], bl);
-                            if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
+                    // a = sum w d (even lanes), e = sum wI d (odd lanes); g = sum w d^2 is the Gram block's diagonal
+                    const double ae = wave_sum2_split(s1, s2, lane);
+                    if (lane < 2) scal[(size_t)k * 4 + lane] = ae;
+                    if (ss > 0 && !no_gram && jr == 0) {
+                        // B(ss - 1): my stores of phase ss - 1 are older than this row's QPL (or more) stores
+                        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QPL < 8 ? QPL : 8) : "memory");
+                        PIPE_LDS_BARRIER();
+                        if (ss > 1 && nvalid_of(ss - 2) > 0)                          // every wave's tiles of block ss - 2 are parked: sum them
+                            pipe_gram_sum_store(W, gred + (size_t)((ss - 2) & 1) * GRED, gwin + (size_t)(by * nsb + ss - 2) * W * W,
+                                                scal + (size_t)(by * BR + (ss - 2) * W) * 4);
+                        if (RW == 1 && nv_prev > 0) {                                 // one row per wave and phase: nothing to put the units beside
+                            pipe_gram_units<QPL, T, PACK>(dprev, qpad, nv_prev, lw, wv, 0, UN, gacc);
+                            pipe_gram_park(gacc, ntiles, gred + (size_t)((ss - 1) & 1) * GRED, wv, lane);
                         }
-                    const int ov = __builtin_amdgcn_readlane(pov, bl);
-                    if (lane == 0) povf[k] = ov;
-                } else {
-                    PIPE_PIN_ROW(onext);
+                    }
                 }
-#pragma unroll
-                for (int j = 0; j < QPL; ++j) ocur[j] = onext[j];
+                PIPE_TL_MARK(pa, t, ss < 3 ? ss : 3);
             }
-            MCSAS_STAMP(pp1);
-            PIPE_TL_MARK(pa, t, 2 * (ss & 1));
-            if (!no_gram) PIPE_LDS_BARRIER();                     // the sub-window's rows are in LDS
-            MCSAS_STAMP(pp2);
-            const int sub = by * nsb + ss;
-            const int64_t left = max_iter - (w * Kb + (int64_t)sub * W);
-            const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
-            if (nvalid > 1 && !no_gram)                           // uniform in the block
-                pipe_prod_gram_lds<QPL>(dbuf, dstr, W, nvalid, lw, gred, glb(pa.gwin) + (((size_t)rep * 2 + buf) * Kb + (size_t)sub * W) * W);
-            // (the next sub-window's rows overwrite dbuf only behind the reduction's first barrier, which every wave
-            // passes after its last operand read; gred is written again behind the next rows -> Gram barrier)
-            MCSAS_STAMP(pp3);
-            PIPE_TL_MARK(pa, t, 2 * (ss & 1) + 1);
-#ifdef MCSAS_STAMPS
-            tg += (pp3 - pp2); tb += (pp2 - pp1);
-#endif
-        }
-#ifdef MCSAS_STAMPS
-        if (by == 0 && tid == 0) {
-            PipeChain &chs = pa.chains[rep];
-            atomicAdd((unsigned long long *)&chs.dbg[8], (unsigned long long)(pp3 - pp0 - tg - tb));
-            atomicAdd((unsigned long long *)&chs.dbg[9], (unsigned long long)tb);
-            atomicAdd((unsigned long long *)&chs.dbg[10], (unsigned long long)tg);
-            atomicAdd((unsigned long long *)&chs.dbg[11], 1ull);
-        }
-#endif
+            // ---- the tail: block nsb - 2 is summed, the last sub-window's Gram block has nothing to run beside
+            if (!no_gram) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PIPE_LDS_BARRIER();                                   // B(nsb - 1)
+                if (nsb > 1 && nvalid_of(nsb - 2) > 0)
+                    pipe_gram_sum_store(W, gred + (size_t)((nsb - 2) & 1) * GRED, gwin + (size_t)(by * nsb + nsb - 2) * W * W,
+                                        scal + (size_t)(by * BR + (nsb - 2) * W) * 4);
+                const int nv = nvalid_of(nsb - 1);
+                if (nv > 0) {                                         // uniform in the block
+                    const auto dlast = dwin + (size_t)(by * BR + (nsb - 1) * W) * qpad;
+                    // batches of UCAP units, the next batch's operands requested before this one's MFMAs
+                    v2f64 G2[PIPE_GRAM_PREF];
+                    pipe_gram_fetch<QPL, T, PACK>(dlast, qpad, nv, wv, 0, UN < UCAP ? UN : UCAP, G);
+                    for (int u = 0; u < UN; u += 2 * UCAP) {
+                        const int n0 = UN - u < UCAP ? UN - u : UCAP;
+                        const int un = u + UCAP, n1 = un < UN ? (UN - un < UCAP ? UN - un : UCAP) : 0;
+                        if (n1 > 0) pipe_gram_fetch<QPL, T, PACK>(dlast, qpad, nv, wv, un, n1, G2);
+                        pipe_gram_consume<QPL, T, PACK>(G, nv, lw, wv, u, n0, gacc);
+                        const int u2 = u + 2 * UCAP, n2 = u2 < UN ? (UN - u2 < UCAP ? UN - u2 : UCAP) : 0;
+                        if (n2 > 0) pipe_gram_fetch<QPL, T, PACK>(dlast, qpad, nv, wv, u2, n2, G);
+                        if (n1 > 0) pipe_gram_consume<QPL, T, PACK>(G2, nv, lw, wv, un, n1, gacc);
+                    }
+                    pipe_gram_park(gacc, ntiles, gred + (size_t)((nsb - 1) & 1) * GRED, wv, lane);
+                    PIPE_LDS_BARRIER();
+                    pipe_gram_sum_store(W, gred + (size_t)((nsb - 1) & 1) * GRED, gwin + (size_t)(by * nsb + nsb - 1) * W * W,
+                                        scal + (size_t)(by * BR + (nsb - 1) * W) * 4);
+                }
+            }
+        };
+        if (W == 24) rows_and_gram(std::integral_constant<int, 2>{}, std::integral_constant<bool, true>{});
+        else if (W <= 16) rows_and_gram(std::integral_constant<int, 1>{}, std::integral_constant<bool, false>{});
+        else rows_and_gram(std::integral_constant<int, 2>{}, std::integral_constant<bool, false>{});
+        PIPE_TL_MARK(pa, t, 3);
         return;
     }
 
@@ -845,7 +981,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
             d[j] = nwv[j] - ocur[j];
             dr[WAVE * j] = d[j];
             const double wd = lw[iq] * d[j];
-            s1 += wd; s2 += lwI[iq] * d[j]; s3 += wd * d[j];
+            s1 += wd; s2 = fma(lwI[iq], d[j], s2); s3 = fma(wd, d[j], s3);
         }
         wave_sum3(s1, s2, s3);
         if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
@@ -962,7 +1098,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
                 const double wf = gw_[lane + WAVE * j] * ft[j];
-                s1 += wf; s2 += wf * ft[j]; s3 += gwI_[lane + WAVE * j] * ft[j];
+                s1 += wf; s2 = fma(wf, ft[j], s2); s3 = fma(gwI_[lane + WAVE * j], ft[j], s3);
                 gft[lane + WAVE * j] = ft[j]; gwft[lane + WAVE * j] = wf;
                 lft[lane + WAVE * j] = ft[j];                 // the end-of-attempt code below reads ft from LDS
             }
@@ -1114,12 +1250,12 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 const double *Gs = Gl + (size_t)(s & 1) * W * W;
                 int start = 0, nacc_sub = 0;
                 for (;;) {
-                    const double SCt = SC + sc0, SICt = SIC + sc1, SCCt = SCC + (2. * h + sc2);
+                    const double SCt = SC + sc0, SICt = SIC + sc1, SCCt = SCC + fma(2., h, sc2);
                     // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
                     double S = cSII, num = SICt, den = SCCt;
                     if (find_bg) {
-                        const double numc = SICt - cSIoSw * SCt, denc = SCCt - SCt * cinvSw * SCt;
-                        const bool neg_b = pos_bg && (cSI * denc - numc * SCt < 0.);
+                        const double numc = fma(-cSIoSw, SCt, SICt), denc = fma(-(SCt * cinvSw), SCt, SCCt);
+                        const bool neg_b = pos_bg && (fma(cSI, denc, -(numc * SCt)) < 0.);
                         if (!neg_b) { S = cScen; num = numc; den = denc; }
                     }
                     const bool cand = in && g >= start;
@@ -1227,7 +1363,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
                     const double f = lft[lane + WAVE * j], wf = lwft[lane + WAVE * j];
-                    s1 += wf; s2 += wf * f; s3 += gwI_[lane + WAVE * j] * f;
+                    s1 += wf; s2 = fma(wf, f, s2); s3 = fma(gwI_[lane + WAVE * j], f, s3);
                 }
                 wave_sum3(s1, s2, s3);
                 SC = s1; SCC = s2; SIC = s3;
@@ -1251,7 +1387,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             for (int j = 0; j < QPL; ++j) {
                 ft[j] = lft[lane + WAVE * j];
                 const double wf = gw_[lane + WAVE * j] * ft[j];
-                s1 += wf; s2 += wf * ft[j]; s3 += gwI_[lane + WAVE * j] * ft[j];
+                s1 += wf; s2 = fma(wf, ft[j], s2); s3 = fma(gwI_[lane + WAVE * j], ft[j], s3);
             }
             wave_sum3(s1, s2, s3);
             cur = solve_fit(a, s1, s2, s3);

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64, (QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1) void 
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
                 double wt = lw[lane + WAVE * j] * ft[j];
-                s1 += wt; s2 += wt * ft[j]; s3 += lwI[lane + WAVE * j] * ft[j];
+                s1 += wt; s2 = fma(wt, ft[j], s2); s3 = fma(lwI[lane + WAVE * j], ft[j], s3);
             }
             wave_sum3(s1, s2, s3);
             cur = solve_fit(a, s1, s2, s3);
@@ -152,14 +152,14 @@ __global__ __launch_bounds__(64, (QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1) void 
                     // three modes — at most one ulp per accepted move away from the reference's order
                     test[j] = ft[j] + (inew[j] - test[j]);
                     double wt = lw[lane + WAVE * j] * test[j];
-                    s1 += wt; s2 += wt * test[j]; s3 += lwI[lane + WAVE * j] * test[j];
+                    s1 += wt; s2 = fma(wt, test[j], s2); s3 = fma(lwI[lane + WAVE * j], test[j], s3);
                 }
                 wave_sum3(s1, s2, s3);
                 // s1 = Σ w C, s2 = Σ w C², s3 = Σ w I C of the candidate (mcsas.py:376)
                 double S = a.SII, num = s3, den = s2;
                 if (a.find_bg) {
-                    const double numc = s3 - SIoSw * s1, denc = s2 - s1 * invSw * s1;
-                    const bool neg_b = a.pos_bg && (a.SI * denc - numc * s1 < 0.);
+                    const double numc = fma(-SIoSw, s1, s3), denc = fma(-(s1 * invSw), s1, s2);
+                    const bool neg_b = a.pos_bg && (fma(a.SI, denc, -(numc * s1)) < 0.);
                     if (!neg_b) { S = Scen; num = numc; den = denc; }
                 }
                 if (num * num > (S - X) * den) {                                   // mcsas.py:379-390
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64, (QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1) void 
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
                 double wt = lw[lane + WAVE * j] * ft[j];
-                s1 += wt; s2 += wt * ft[j]; s3 += lwI[lane + WAVE * j] * ft[j];
+                s1 += wt; s2 = fma(wt, ft[j], s2); s3 = fma(lwI[lane + WAVE * j], ft[j], s3);
             }
             wave_sum3(s1, s2, s3);
             cur = solve_fit(a, s1, s2, s3);

@@ -198,7 +198,7 @@ __device__ __forceinline__ void wg_producer(const ChainArgs &a, const WgGeom &g,
                         d[j] = nw - d[j];
                         dr[WAVE * j] = d[j];
                         const double wd = sh.lw[i] * d[j];
-                        s1 += wd; s2 += sh.lwI[i] * d[j]; s3 += wd * d[j];
+                        s1 += wd; s2 = fma(sh.lwI[i], d[j], s2); s3 = fma(wd, d[j], s3);
                     }
                     wave_sum3(s1, s2, s3);
                     if (lane == 0) {
@@ -271,7 +271,7 @@ __device__ __forceinline__ void wg_scanner(const ChainArgs &a, const WgGeom &g, 
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
                 const double wf = sh.lw[lane + WAVE * j] * ft[j];
-                s1 += wf; s2 += wf * ft[j]; s3 += sh.lwI[lane + WAVE * j] * ft[j];
+                s1 += wf; s2 = fma(wf, ft[j], s2); s3 = fma(sh.lwI[lane + WAVE * j], ft[j], s3);
                 lft[WAVE * j] = ft[j]; lwft[WAVE * j] = wf;
             }
             wave_sum3(s1, s2, s3);
@@ -320,12 +320,12 @@ __device__ __forceinline__ void wg_scanner(const ChainArgs &a, const WgGeom &g, 
                     (void)gslot;
                     const int kg = (k + g < K) ? k + g : K - 1;
                     const double *sc = sbase + kg * 4;
-                    const double SCt = SC + sc[0], SICt = SIC + sc[1], SCCt = SCC + (2. * h + sc[2]);
+                    const double SCt = SC + sc[0], SICt = SIC + sc[1], SCCt = SCC + fma(2., h, sc[2]);
                     // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
                     double S = a.SII, num = SICt, den = SCCt;
                     if (a.find_bg) {
-                        const double numc = SICt - SIoSw * SCt, denc = SCCt - SCt * invSw * SCt;
-                        const bool neg_b = a.pos_bg && (a.SI * denc - numc * SCt < 0.);
+                        const double numc = fma(-SIoSw, SCt, SICt), denc = fma(-(SCt * invSw), SCt, SCCt);
+                        const bool neg_b = a.pos_bg && (fma(a.SI, denc, -(numc * SCt)) < 0.);
                         if (!neg_b) { S = Scen; num = numc; den = denc; }
                     }
                     const bool acc_g = (g < gcount) && (num * num > (S - X) * den);   // chi²_t < chi² (mcsas.py:379)
@@ -377,7 +377,7 @@ __device__ __forceinline__ void wg_scanner(const ChainArgs &a, const WgGeom &g, 
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {
                         const double f = lft[WAVE * j], wf = lwft[WAVE * j];
-                        s1 += wf; s2 += wf * f; s3 += sh.lwI[lane + WAVE * j] * f;
+                        s1 += wf; s2 = fma(wf, f, s2); s3 = fma(sh.lwI[lane + WAVE * j], f, s3);
                     }
                     wave_sum3(s1, s2, s3);
                     SC = s1; SCC = s2; SIC = s3;
@@ -401,7 +401,7 @@ __device__ __forceinline__ void wg_scanner(const ChainArgs &a, const WgGeom &g, 
             for (int j = 0; j < QPL; ++j) {
                 ft[j] = lft[WAVE * j];
                 const double wf = sh.lw[lane + WAVE * j] * ft[j];
-                s1 += wf; s2 += wf * ft[j]; s3 += sh.lwI[lane + WAVE * j] * ft[j];
+                s1 += wf; s2 = fma(wf, ft[j], s2); s3 = fma(sh.lwI[lane + WAVE * j], ft[j], s3);
             }
             wave_sum3(s1, s2, s3);
             cur = solve_fit(a, s1, s2, s3);

@@ -115,6 +115,20 @@ __device__ __forceinline__ double wave_sum8_transposed(const double (&acc)[8], i
     return sum_xor32(a1);
 }
 
+// Two sums for the price of ~1.2: the first exchange hands every even lane its neighbour's a and every odd lane its
+// neighbour's b, the five exchanges behind it stay within a parity.  Out: the wave total of a in every even lane, of b in
+// every odd lane.
+__device__ __forceinline__ double wave_sum2_split(double a, double b, int lane) {
+    const bool b0 = lane & 1;
+    const double keep = b0 ? b : a, send = b0 ? a : b;
+    double t = keep + dpp_f64<0xB1>(send);                   // quad_perm [1,0,3,2]
+    t += dpp_f64<0x4E>(t);                                   // quad_perm [2,3,0,1]
+    t += lane_xor4(t);
+    t += dpp_f64<0x128>(t);                                  // row_ror:8 == lane xor 8
+    t = sum_xor16(t);
+    return sum_xor32(t);
+}
+
 __device__ __forceinline__ double wave_min(double v) {
     v = fmin(v, __shfl_xor(v, 1)); v = fmin(v, __shfl_xor(v, 2));
     v = fmin(v, __shfl_xor(v, 4)); v = fmin(v, __shfl_xor(v, 8));

@@ -59,50 +59,81 @@ MCSAS_HD void sincos_fast(double x, double *sn, double *cs) {
     *cs = ((q + 1) & 2) ? -co : co;
 }
 
-// branch-free core of sincos_fast for |x| < 2^20 (the caller guarantees the range): two-term
-// Cody-Waite reduction (the third term is < 2e-27 absolute for n < 2^20) + the same kernels
-MCSAS_HD void sincos_core(double x, double *sn, double *cs) {
+// The two kernels of sincos_core without the final quadrant selection: for |x| < 2^20 (the caller guarantees the
+// range) x = n pi/2 + r by a two-term Cody-Waite reduction (the third term is < 2e-27 absolute for n < 2^20),
+// *s = sin r, *c = cos r (fdlibm kernels, |r| <= pi/4), *q = n.  sin x, cos x = +-s / +-c, swapped when n is odd.
+MCSAS_HD void sincos_poly(double x, double *s, double *c, int *q) {
     const double TWO_OVER_PI = 6.36619772367581382433e-01;
     const double P1 = 1.57079632679489655800e+00;
     const double P2 = 6.12323399573676603587e-17;
     double n = rint(x * TWO_OVER_PI);
     double r = fma(-n, P1, x);
     r = fma(-n, P2, r);
-    int q = (int)n;
+    *q = (int)n;
     double r2 = r * r;
     double ps = fma(r2, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
     ps = fma(r2, ps, 2.75573137070700676789e-06);
     ps = fma(r2, ps, -1.98412698298579493134e-04);
     ps = fma(r2, ps, 8.33333333332248946124e-03);
     ps = fma(r2, ps, -1.66666666666666324348e-01);
-    double s = fma(r * r2, ps, r);
+    *s = fma(r * r2, ps, r);
     double pc = fma(r2, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
     pc = fma(r2, pc, -2.75573143513906633035e-07);
     pc = fma(r2, pc, 2.48015872894767294178e-05);
     pc = fma(r2, pc, -1.38888888888741095749e-03);
     pc = fma(r2, pc, 4.16666666666666019037e-02);
-    double c = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));
+    *c = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));
+}
+
+// branch-free core of sincos_fast for |x| < 2^20: sincos_poly + the quadrant selection
+MCSAS_HD void sincos_core(double x, double *sn, double *cs) {
+    double s, c;
+    int q;
+    sincos_poly(x, &s, &c, &q);
     double so = (q & 1) ? c : s;
     double co = (q & 1) ? s : c;
     *sn = (q & 2) ? -so : so;
     *cs = ((q + 1) & 2) ? -co : co;
 }
 
-// sincos_core over N independent arguments, written stage by stage so that the N dependent chains are issued
-// interleaved (one chain after the other runs at the fp64 pipe's latency, not its issue rate).  The operations
-// and their order per element are exactly sincos_core's: the results are bit-identical.
-template <int N>
-MCSAS_HD void sincos_core_n(const double (&x)[N], double (&sn)[N], double (&cs)[N]) {
-    const double TWO_OVER_PI = 6.36619772367581382433e-01;
-    const double P1 = 1.57079632679489655800e+00;
-    const double P2 = 6.12323399573676603587e-17;
-    double n[N], r[N], r2[N], ps[N], pc[N];
-    int q[N];
+// |sin x - x cos x| up to its sign, for callers that square it (the sphere form factor): with x = n pi/2 + r,
+//   n = 0, 2 (mod 4):  sin x - x cos x = +-(sin r - x cos r),      n = 1, 3:  +-(cos r + x sin r),
+// and fma(-x, -c, -s) == -fma(-x, c, s) bit for bit, so the square equals that of fma(-x, cos x, sin x) taken
+// from sincos_core — without its two sign flips and with one selection instead of two.
+MCSAS_HD double sin_minus_xcos_abs(double x) {
+    double s, c;
+    int q;
+    sincos_poly(x, &s, &c, &q);
+    const double fe = fma(-x, c, s), fo = fma(x, s, c);
+    return (q & 1) ? fo : fe;
+}
+
+// sin x - x cos x with its sign (callers that add several such terms: the core-shell ellipsoid): the same
+// selection, then one sign flip for n = 2, 3 (mod 4).  Bit-identical to fma(-x, cos x, sin x) from sincos_core.
+MCSAS_HD double sin_minus_xcos(double x) {
+    double s, c;
+    int q;
+    sincos_poly(x, &s, &c, &q);
+    const double fe = fma(-x, c, s), fo = fma(x, s, c);
+    const double h = (q & 1) ? fo : fe;
+    return (q & 2) ? -h : h;
+}
+
 #if defined(__HIPCC__)
 #define MCSAS_UNROLL _Pragma("unroll")
 #else
 #define MCSAS_UNROLL
 #endif
+
+// sincos_poly over N independent arguments, written stage by stage so that the N dependent chains are issued
+// interleaved (one chain after the other runs at the fp64 pipe's latency, not its issue rate).  The operations
+// and their order per element are exactly sincos_poly's: the results are bit-identical.
+template <int N>
+MCSAS_HD void sincos_poly_n(const double (&x)[N], double (&s)[N], double (&c)[N], int (&q)[N]) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double P1 = 1.57079632679489655800e+00;
+    const double P2 = 6.12323399573676603587e-17;
+    double n[N], r[N], r2[N], ps[N], pc[N];
     MCSAS_UNROLL for (int i = 0; i < N; ++i) n[i] = rint(x[i] * TWO_OVER_PI);
     MCSAS_UNROLL for (int i = 0; i < N; ++i) r[i] = fma(-n[i], P1, x[i]);
     MCSAS_UNROLL for (int i = 0; i < N; ++i) r[i] = fma(-n[i], P2, r[i]);
@@ -118,15 +149,37 @@ MCSAS_HD void sincos_core_n(const double (&x)[N], double (&sn)[N], double (&cs)[
     MCSAS_UNROLL for (int i = 0; i < N; ++i) ps[i] = fma(r2[i], ps[i], -1.66666666666666324348e-01);
     MCSAS_UNROLL for (int i = 0; i < N; ++i) pc[i] = fma(r2[i], pc[i], 4.16666666666666019037e-02);
     MCSAS_UNROLL for (int i = 0; i < N; ++i) {
-        const double s = fma(r[i] * r2[i], ps[i], r[i]);
-        const double c = fma(r2[i] * r2[i], pc[i], fma(-0.5, r2[i], 1.0));
-        const double so = (q[i] & 1) ? c : s;
-        const double co = (q[i] & 1) ? s : c;
+        s[i] = fma(r[i] * r2[i], ps[i], r[i]);
+        c[i] = fma(r2[i] * r2[i], pc[i], fma(-0.5, r2[i], 1.0));
+    }
+}
+
+// sincos_core over N independent arguments (sincos_poly_n + the quadrant selections): bit-identical per element
+template <int N>
+MCSAS_HD void sincos_core_n(const double (&x)[N], double (&sn)[N], double (&cs)[N]) {
+    double s[N], c[N];
+    int q[N];
+    sincos_poly_n<N>(x, s, c, q);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) {
+        const double so = (q[i] & 1) ? c[i] : s[i];
+        const double co = (q[i] & 1) ? s[i] : c[i];
         sn[i] = (q[i] & 2) ? -so : so;
         cs[i] = ((q[i] + 1) & 2) ? -co : co;
     }
-#undef MCSAS_UNROLL
 }
+
+// sin_minus_xcos_abs over N independent arguments: bit-identical per element
+template <int N>
+MCSAS_HD void sin_minus_xcos_abs_n(const double (&x)[N], double (&g)[N]) {
+    double s[N], c[N];
+    int q[N];
+    sincos_poly_n<N>(x, s, c, q);
+    MCSAS_UNROLL for (int i = 0; i < N; ++i) {
+        const double fe = fma(-x[i], c[i], s[i]), fo = fma(x[i], s[i], c[i]);
+        g[i] = (q[i] & 1) ? fo : fe;
+    }
+}
+#undef MCSAS_UNROLL
 
 // Bessel J1, the Cephes algorithm (the one behind scipy.special.j1 that the reference calls,
 // cylindersisotropic.py:74, kholodenko.py:43): rational approximation on [0, 5], Hankel asymptotic

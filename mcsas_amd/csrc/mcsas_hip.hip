@@ -822,6 +822,87 @@ extern "C" int mcsas_hip_plan_total_steps(mcsas_plan *pl, int64_t *steps) {
     return MCSAS_OK;
 }
 
+static int analyse_one(const mcsas_problem *p, mcsas_result *res) {
+    mcsas_plan *pl = nullptr;
+    int rc = mcsas_hip_plan_create(p, &pl);
+    if (rc) return rc;
+    rc = mcsas_hip_plan_launch(pl, nullptr);
+    if (!rc) rc = mcsas_hip_plan_fetch(pl, res);
+    mcsas_hip_plan_destroy(pl);
+    return rc;
+}
+
+// repetitions [first, first + count) of device-list entry `index` (contiguous blocks, sizes differ by at most one)
+extern "C" int mcsas_hip_shard(int32_t n_reps, int32_t n_devices, int32_t index, int32_t *first, int32_t *count) {
+    if (n_reps < 0 || n_devices < 1 || index < 0 || index >= n_devices || !first || !count) return fail(MCSAS_EINVAL, "bad argument");
+    const int32_t base = n_reps / n_devices, extra = n_reps % n_devices;
+    *count = base + (index < extra ? 1 : 0);
+    *first = index * base + (index < extra ? index : extra);
+    return MCSAS_OK;
+}
+
+// McSAS.analyse's repetition loop (mcsas.py:214-262) over several GPUs: one host thread, one plan and one stream per
+// device, each running a contiguous block of repetitions under its global chain ids; every block lands in the caller's
+// (…, numReps) arrays at its place.  No data-path exchange between the devices: the blocks share read-only inputs only.
+static int analyse_sharded(const mcsas_problem *p, mcsas_result *res) {
+    if (res->struct_size != sizeof(mcsas_result)) return fail(MCSAS_EINVAL, "mcsas_result size mismatch");
+    const int G = p->n_devices;
+    if (G > MCSAS_MAX_DEVICES) return fail(MCSAS_EINVAL, "n_devices %d > %d", G, MCSAS_MAX_DEVICES);
+    if (p->n_reps < 1 || p->n_contrib < 1 || p->nq < 1) return fail(MCSAS_EINVAL, "n_reps, n_contrib and nq must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(MCSAS_ENODEV, "no HIP device available");
+    for (int g = 0; g < G; ++g)
+        if (p->devices[g] < 0 || p->devices[g] >= ndev) return fail(MCSAS_ENODEV, "devices[%d] = %d, %d present", g, p->devices[g], ndev);
+    const size_t R = p->n_reps, N = p->n_contrib, P = p->n_active, Q = p->nq;
+    struct Shard {
+        mcsas_problem prob; mcsas_result out;
+        int32_t first = 0, count = 0; int rc = 0; std::string err;
+        std::vector<double> contribs, fit, chisq, scaling, background, seconds;
+        std::vector<int64_t> num_iter, num_moves, draws;
+        std::vector<int32_t> attempts, converged;
+    };
+    std::vector<Shard> sh(G);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) {
+        Shard &s = sh[g];
+        mcsas_hip_shard((int32_t)R, G, g, &s.first, &s.count);
+        if (s.count == 0) continue;
+        s.prob = *p;
+        s.prob.n_devices = 0; s.prob.device = p->devices[g];
+        s.prob.n_reps = s.count; s.prob.rep_offset = p->rep_offset + s.first;
+        if (p->replay_stream) s.prob.replay_stream = p->replay_stream + (size_t)s.first * p->replay_len;
+        const size_t Rg = s.count;
+        memset(&s.out, 0, sizeof s.out);
+        s.out.struct_size = sizeof(mcsas_result);
+#define SHBUF(f) do { if (res->f) { s.f.resize(Rg); s.out.f = s.f.data(); } } while (0)
+        if (res->contribs) { s.contribs.resize(N * P * Rg); s.out.contribs = s.contribs.data(); }
+        if (res->fit) { s.fit.resize(Q * Rg); s.out.fit = s.fit.data(); }
+        SHBUF(chisq); SHBUF(scaling); SHBUF(background); SHBUF(seconds); SHBUF(num_iter); SHBUF(num_moves); SHBUF(draws);
+        SHBUF(attempts); SHBUF(converged);
+#undef SHBUF
+        th.emplace_back([&s]() {
+            s.rc = analyse_one(&s.prob, &s.out);
+            if (s.rc) s.err = g_err;                          // (thread-local in the worker)
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int g = 0; g < G; ++g)
+        if (sh[g].rc) return fail(sh[g].rc, "device %d (repetitions %d..%d): %s", p->devices[g], sh[g].first, sh[g].first + sh[g].count - 1, sh[g].err.c_str());
+    for (int g = 0; g < G; ++g) {
+        const Shard &s = sh[g];
+        const size_t Rg = s.count, f0 = s.first;
+        if (res->contribs) for (size_t i = 0; i < N * P; ++i) for (size_t r = 0; r < Rg; ++r) res->contribs[i * R + f0 + r] = s.contribs[i * Rg + r];
+        if (res->fit) for (size_t k = 0; k < Q; ++k) for (size_t r = 0; r < Rg; ++r) res->fit[k * R + f0 + r] = s.fit[k * Rg + r];
+        for (size_t r = 0; r < Rg; ++r) {
+#define SHCOPY(f) do { if (res->f) res->f[f0 + r] = s.f[r]; } while (0)
+            SHCOPY(chisq); SHCOPY(scaling); SHCOPY(background); SHCOPY(seconds); SHCOPY(num_iter); SHCOPY(num_moves); SHCOPY(draws);
+            SHCOPY(attempts); SHCOPY(converged);
+#undef SHCOPY
+        }
+    }
+    return MCSAS_OK;
+}
+
 extern "C" int mcsas_hip_analyse(const mcsas_problem *p, mcsas_result *res) {
     if (!res) return fail(MCSAS_EINVAL, "null result");
     if (p && p->n_active == 0) {
@@ -847,13 +928,8 @@ extern "C" int mcsas_hip_analyse(const mcsas_problem *p, mcsas_result *res) {
         if (res->draws) res->draws[0] = 0;
         return MCSAS_OK;
     }
-    mcsas_plan *pl = nullptr;
-    int rc = mcsas_hip_plan_create(p, &pl);
-    if (rc) return rc;
-    rc = mcsas_hip_plan_launch(pl, nullptr);
-    if (!rc) rc = mcsas_hip_plan_fetch(pl, res);
-    mcsas_hip_plan_destroy(pl);
-    return rc;
+    if (p && p->struct_size == sizeof(mcsas_problem) && p->n_devices > 1) return analyse_sharded(p, res);
+    return analyse_one(p, res);
 }
 
 // ------------------------------------------------------------------------------ model.calc

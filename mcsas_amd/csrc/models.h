@@ -7,6 +7,10 @@
 #include "fastmath.h"
 #include "../../include/mcsas_hip.h"
 
+#ifndef MCSAS_ROW_GROUP
+#define MCSAS_ROW_GROUP 4       // sphere rows: q slots per lane evaluated in one interleaved group
+#endif
+
 namespace mcsas {
 
 // kernel-argument view of the model half of mcsas_problem
@@ -92,30 +96,30 @@ template <> struct Contrib<MCSAS_MODEL_SPHERE> {
         o.invr3 = readlane_f64(invr3, lane); o.fast = __builtin_amdgcn_readlane(fast, lane);
         return o;
     }
-    // branch-free evaluation, valid when `fast`: 1/x^3 from the two precomputed reciprocals
+    // branch-free evaluation, valid when `fast`: 1/x^3 from the two precomputed reciprocals; sin x - x cos x up to its
+    // sign (it is squared: fastmath.h, sin_minus_xcos_abs)
     __device__ __forceinline__ double intensity_fast(double q, double q3inv) const {
-        double x = q * r, sn, cs;
-        sincos_core(x, &sn, &cs);
-        double f = (3. * (sn - x * cs)) * (q3inv * invr3);
+        const double x = q * r;
+        const double f = (3. * sin_minus_xcos_abs(x)) * (q3inv * invr3);
         return f * f * w;
     }
-    // the same for N points at once, the N chains interleaved (fastmath.h: sincos_core_n); bit-identical per point
+    // the same for N points at once, the N chains interleaved (fastmath.h: sincos_poly_n); bit-identical per point
     template <int N>
     __device__ __forceinline__ void intensity_fast_n(const double (&q)[N], const double (&q3inv)[N], double (&out)[N]) const {
-        double x[N], sn[N], cs[N];
+        double x[N], g[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) x[i] = q[i] * r;
-        sincos_core_n<N>(x, sn, cs);
+        sin_minus_xcos_abs_n<N>(x, g);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const double f = (3. * (sn[i] - x[i] * cs[i])) * (q3inv[i] * invr3);
+            const double f = (3. * g[i]) * (q3inv[i] * invr3);
             out[i] = f * f * w;
         }
     }
     __device__ __forceinline__ double intensity(double q, const double *) const {
         double x = q * r, sn, cs;
         sincos_fast(x, &sn, &cs);
-        double f = div_fast(3. * (sn - x * cs), x * x * x);  // sphere.py:62
+        double f = div_fast(3. * fma(-x, cs, sn), x * x * x);  // sphere.py:62
         return f * f * w;
     }
 };
@@ -317,10 +321,7 @@ template <> struct Contrib<MCSAS_MODEL_ELL_CS> {
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
                 const double xc = q[j] * Rc, xt = q[j] * Rt;
-                double sc, cc, st, ct;
-                sincos_core(xc, &sc, &cc);
-                sincos_core(xt, &st, &ct);
-                const double g = fma(C1, fma(-xc, cc, sc), C2 * fma(-xt, ct, st));
+                const double g = fma(C1, sin_minus_xcos(xc), C2 * sin_minus_xcos(xt));
                 acc[j] = fma(g, g, acc[j]);
             }
         }
@@ -447,7 +448,7 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
                     // (no cancellation for small z; one transcendental call per point instead of two)
                     const double u = expm1_neg_fast(-z);
                     const double fz = (sn * invF) * div_fast(2. * (1.0 + u), -u * (2.0 + u));
-                    pa = fma(tab[16 + i], fz * (1.0 - z * invx), pa);
+                    pa = fma(tab[16 + i], fz * fma(-z, invx, 1.0), pa);
                 }
                 acc = fma(pa, hw, acc);
             }
@@ -500,7 +501,7 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
                     // sinh(e z)/(e sinh z) = exp(-(1-e) z) (1 - exp(-2 e z)) / (e (1 - exp(-2 z))); e -> 0: 2 z exp(-z)/(1-exp(-2z))
                     const double fz = (e > 0.) ? exp(-a1 * z) * (-expm1_neg_fast(-2. * e * z)) / (e * den)
                                                : 2. * z * exp(-z) / den;
-                    pa = fma(tab[16 + i], fz * (1.0 - z * invx), pa);
+                    pa = fma(tab[16 + i], fz * fma(-z, invx, 1.0), pa);
                 }
                 acc = fma(pa, hw, acc);
                 left = right;
@@ -581,9 +582,7 @@ template <> struct Contrib<MCSAS_MODEL_ELL_ISO> {
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
                 const double x = q[j] * R;
-                double sn, cs;
-                sincos_core(x, &sn, &cs);
-                const double g = D * fma(-x, cs, sn);
+                const double g = D * sin_minus_xcos_abs(x);
                 acc[j] = fma(g, g, acc[j]);
             }
         }
@@ -775,10 +774,19 @@ template <int QPL> struct RowEval<MCSAS_MODEL_SPHERE, QPL> {
             // all operands first, then the QPL evaluations in ONE basic block: their dependent chains interleave and a
             // single wave keeps its SIMD's fp64 pipe busy (one evaluation after the other is latency bound: ~8 cycles
             // per instruction instead of ~4)
-            double qq[QPL], q3[QPL];
+            // (four at a time: four interleaved chains keep the pipe busy as well as eight do and leave the registers of the
+            // other four to the caller — the pipeline's producer carries Gram accumulators across this call)
+            constexpr int RG = QPL < MCSAS_ROW_GROUP ? QPL : MCSAS_ROW_GROUP;
 #pragma unroll
-            for (int j = 0; j < QPL; ++j) { qq[j] = t.q[lane + WAVE * j]; q3[j] = t.q3inv[lane + WAVE * j]; }
-            c.template intensity_fast_n<QPL>(qq, q3, out);
+            for (int j0 = 0; j0 < QPL; j0 += RG) {
+                double qq[RG], q3[RG], o[RG];
+#pragma unroll
+                for (int j = 0; j < RG; ++j) { qq[j] = t.q[lane + WAVE * (j0 + j)]; q3[j] = t.q3inv[lane + WAVE * (j0 + j)]; }
+                c.template intensity_fast_n<RG>(qq, q3, o);
+#pragma unroll
+                for (int j = 0; j < RG; ++j) out[j0 + j] = o[j];
+                if (j0 + RG < QPL) __builtin_amdgcn_sched_barrier(0);
+            }
         } else {
             asm volatile("" ::: "memory");                    // keeps the optimiser from folding the two loops into one with a branch per element
 #pragma unroll

@@ -12,7 +12,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
-from ._lib import MAX_ACTIVE, MAX_PARAMS, Problem, Result, as_dp, check, f64
+from ._lib import MAX_ACTIVE, MAX_DEVICES, MAX_PARAMS, Problem, Result, as_dp, check, f64
 
 MODEL_SPHERE, MODEL_CYL_ISO, MODEL_ELL_CS, MODEL_KHOLODENKO = 0, 1, 2, 3
 MODEL_ELL_ISO, MODEL_SPH_CS, MODEL_GAUSS_CHAIN, MODEL_LMA_SPHERE = 4, 5, 6, 7
@@ -56,7 +56,8 @@ class Settings:
     # execution knobs (no reference counterpart)
     seed: int = 0
     rep_offset: int = 0
-    device: int = -1
+    device: int = -1                   # HIP device ordinal (-1: current)
+    devices: tuple = ()                # several GPUs: analyse() runs contiguous blocks of repetitions on these at once
     waves_per_chain: int = 0
     cache_intensities: int = -1
     exec_mode: int = 0                 # MCSAS_EXEC_*: 0 auto, 1 wave, 2 workgroup, 3 pipeline
@@ -111,6 +112,11 @@ class HipProblem:
         if stop is not None:
             p.stop = C.pointer(stop)
         p.device = int(st.device)
+        devs = tuple(int(d) for d in (st.devices or ()))
+        if len(devs) > MAX_DEVICES:
+            raise ValueError("at most %d devices, got %d" % (MAX_DEVICES, len(devs)))
+        p.n_devices = len(devs)
+        _fill(p.devices, devs, len(devs))
         p.waves_per_chain = int(st.waves_per_chain)
         p.cache_intensities = int(st.cache_intensities)
         p.exec_mode = int(st.exec_mode)
@@ -297,3 +303,10 @@ def rebin(x, f, fu, n_bin, device=-1):
 
 def device_count():
     return _lib.load().mcsas_hip_device_count()
+
+
+def shard(n_reps, n_devices, index):
+    """(first, count): the block of repetitions mcsas_hip_analyse gives device-list entry `index`."""
+    first, count = C.c_int32(0), C.c_int32(0)
+    check(_lib.load().mcsas_hip_shard(int(n_reps), int(n_devices), int(index), C.byref(first), C.byref(count)))
+    return first.value, count.value

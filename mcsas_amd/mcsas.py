@@ -58,10 +58,14 @@ class McSAS(object):
         return cls
 
     def __init__(self, seed=None, device=-1, wavesPerChain=0, execMode=0):
+        """`device`: a HIP device ordinal (-1: the current device) or a list of them — the repetitions are then spread
+        over those GPUs by the library (contiguous blocks, mcsas_hip.h: n_devices / devices), results in repetition order
+        as if one device had run them; `histogram()` uses the first of the list."""
         for name, default, rng in _DEFAULTS:
             setattr(self, name, _Setting(name, default, rng))
         self.seed = seed
-        self.device = device
+        self.devices = tuple(int(d) for d in device) if isinstance(device, (list, tuple)) else ()
+        self.device = self.devices[0] if self.devices else int(device)
         self.wavesPerChain = wavesPerChain
         self.execMode = execMode
         self._stop = C.c_int32(0)
@@ -100,7 +104,7 @@ class McSAS(object):
             comp_exp=self.compensationExponent(), conv_crit=self.convergenceCriterion(),
             find_background=self.findBackground.value(), positive_background=self.positiveBackground.value(),
             start_from_minimum=self.startFromMinimum(), max_retries=int(self.maxRetries()),
-            show_incomplete=self.showIncomplete(), seed=seed, device=self.device,
+            show_incomplete=self.showIncomplete(), seed=seed, device=self.device, devices=self.devices,
             waves_per_chain=self.wavesPerChain, exec_mode=self.execMode)
 
     def analyse(self, replay=None):                          # mcsas.py:191-285

@@ -790,6 +790,43 @@ def gen_param_declarations():
     print("G10 written:", ", ".join(out))
 
 
+# ---------------------------------------------------------------- G13 (round 3): the quick-start fit, free-running
+def gen_quickstart(seed=3001):
+    """doc/source/quickstart.rst:66-107: Sphere on testdata/quickstartdemo1.csv, radius range from the data
+    (sphericalSizeEst), 10 repetitions x 300 contributions, convergence criterion 1, background on, ONE histogram with a
+    log x axis (GUI defaults: 50 bins, volume-weighted) — the reference run free (global numpy RNG seeded) through calc(),
+    i.e. analyse() + histogram().  Stored: the data vectors, every repetition's parameter set, the histogram's per-bin
+    mean / std over the repetitions, CDF, observability, moments, and the wall time of calc() in THIS container (the
+    document quotes 36 s on a 2012 iMac, quickstart.rst:106-107)."""
+    import time
+    d = loaddatafile("/root/reference/testdata/quickstartdemo1.csv").getDataObj()
+    dv = data_vectors(d)
+    out = {"data_" + k: v for k, v in dv.items()}
+    m = Sphere(); m.radius.setActiveRange(tuple(d.sphericalSizeEst()))
+    lo, hi = m.radius.activeRange()
+    m.radius.histograms().append(Histogram(m.radius, lo, hi, binCount=50, xscale='log', yweight='vol'))
+    algo = new_algo(numContribs=300, numReps=10, maxIterations=100000, convergenceCriterion=1.0)
+    algo.model = m; algo.data = d
+    quiet_logging(None)
+    np.random.seed(seed)
+    t0 = time.time()
+    algo.calc()
+    wall = time.time() - t0
+    res = algo.result[0]
+    h = m.radius.histograms()[0]
+    out.update(lo=lo, hi=hi, seed=seed, wall_s=wall, contribs=np.array(res["contribs"]),
+               fitMean=np.array(res["fitMeasValMean"]), fitStd=np.array(res["fitMeasValStd"]),
+               scaling=np.array(res["scaling"]), background=np.array(res["background"]), numIter=float(res["numIter"]),
+               times=np.array(res["times"]),
+               h_edges=np.array(h.xLowerEdge), h_width=np.array(h.xWidth), h_mean=np.array(h.xMean),
+               h_bins_full=np.array(h.bins.full), h_bins_mean=np.array(h.bins.mean), h_bins_std=np.array(h.bins.std),
+               h_cdf_mean=np.array(h.cdf.mean), h_cdf_std=np.array(h.cdf.std), h_obs=np.array(h.observability),
+               h_moments=np.array(h.moments.fields, dtype=float))
+    np.savez_compressed(os.path.join(OUT, "g13_quickstart.npz"), **out)
+    print("G13 quick start written: calc() %.1f s here, numIter mean %.0f, scaling %s, background %s" %
+          (wall, out["numIter"], res["scaling"], res["background"]))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     quiet_logging(None)
@@ -815,3 +852,5 @@ if __name__ == "__main__":
         gen_param_declarations()
     if "kho5" in which:
         gen_kholodenko_config5()
+    if "quickstart" in which or not sys.argv[1:]:
+        gen_quickstart()

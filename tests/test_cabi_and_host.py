@@ -167,3 +167,14 @@ def test_histogram_host_binning_matches_reference(golden_dir):
         np.testing.assert_allclose(h.cdf.mean, g[p + "cdf_mean"], rtol=1e-9)
         np.testing.assert_allclose(h.observability, g[p + "obs"], rtol=1e-9)
         np.testing.assert_allclose(np.array(h.moments.fields)[0::2], g[p + "moments"][0::2], rtol=1e-9)
+
+
+def test_shard_rule_of_the_library_is_the_one_of_dist():
+    """mcsas_hip_shard (how mcsas_hip_analyse splits repetitions over a device list) == mcsas_amd.dist.shard_reps (how
+    bench.py's ranks split them): contiguous blocks in order, sizes within one of each other, empty blocks allowed."""
+    from mcsas_amd import dist, engine
+    for n in (0, 1, 5, 13, 50, 400):
+        for g in (1, 2, 3, 8, 16):
+            blocks = [engine.shard(n, g, i) for i in range(g)]
+            assert blocks == [dist.shard_reps(n, g, i) for i in range(g)]
+            assert sum(c for _, c in blocks) == n and all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(g - 1))

@@ -178,6 +178,103 @@ def test_calc_converges_and_histogram_matches_reference():
         np.testing.assert_allclose(np.array(h.moments.fields)[0::2], g[p + "moments"][0::2], rtol=1e-6)
 
 
+def _quickstart_algo(g, reps, seed):
+    lo, hi = float(g["lo"]), float(g["hi"])
+    m, _ = make_models("sphere", [lo], [hi])
+    m.radius.histograms().append(mcsas_amd.Histogram(m.radius, lo, hi, binCount=50, xscale='log', yweight='vol'))
+    algo = mcsas_amd.McSAS(seed=seed)
+    algo.numContribs.setValue(300); algo.numReps.setValue(reps); algo.convergenceCriterion.setValue(1.0)
+    algo.model = m
+    algo.data = mcsas_amd.SASData(g["data_q"], g["data_I"], g["data_sigma"], f_limit=g["data_f_limit"])
+    return algo, m
+
+
+def test_quickstart_acceptance_free_running():
+    """The reference's published workload, end to end and free-running (doc/source/quickstart.rst:66-107): Sphere on
+    quickstartdemo1.csv, 300 contributions, criterion 1, one 50-bin log histogram — here 50 repetitions with the device's
+    Philox stream against the reference's own 10-repetition run (fixture g13, oracle/make_golden.py gen_quickstart):
+    every repetition reaches chi² <= 1, the volume-weighted histogram agrees bin by bin within the two runs' standard
+    errors, and the three populations of the document's ground truth (quickstart.rst:195-199: Gaussians at 8, 40 and
+    100 nm) come out as three separate modes."""
+    g = load("g13_quickstart.npz")
+    algo, m = _quickstart_algo(g, 50, 77)
+    algo.calc()
+    res = algo.result[0]
+    assert res["contribs"].shape == (300, 1, 50)
+    assert (algo.details.chisq <= 1.0).all() and (algo.details.converged == 1).all()
+    h = m.radius.histograms()[0]
+    np.testing.assert_allclose(h.xLowerEdge, g["h_edges"], rtol=1e-14)
+    ours, ours_se = np.asarray(h.bins.mean), np.asarray(h.bins.std) / np.sqrt(50.)
+    ref, ref_se = g["h_bins_mean"], g["h_bins_std"] / np.sqrt(10.)
+    se = np.sqrt(ours_se**2 + ref_se**2) + 0.01 * ref.max()
+    z = (ours - ref) / se
+    assert np.abs(z).max() < 5.0 and np.sqrt(np.mean(z**2)) < 2.0, z
+    # the same mean number of iterations within a factor (the stream differs, the statistics do not)
+    assert 0.6 < res["numIter"] / float(g["numIter"]) < 1.6
+    # total volume fraction and volume-weighted mean radius (Moments.fields[0], [2]) within 2 %
+    mo = np.asarray(h.moments.fields, dtype=float)
+    np.testing.assert_allclose(mo[[0, 2]], g["h_moments"][[0, 2]], rtol=0.02)
+    # three modes: local maxima of the smoothed histogram next to 8+, 40+ and 100 nm (volume weighting on a log axis
+    # moves a Gaussian's mode up: the reference's own histogram peaks at 10.9, 47.6 and 99.5 nm)
+    x = np.asarray(g["h_mean"])
+    sm = np.convolve(ours, [0.25, 0.5, 0.25], mode="same")
+    peaks = [x[i] for i in range(1, 49) if sm[i] > sm[i - 1] and sm[i] >= sm[i + 1] and sm[i] > 0.05 * sm.max()]
+    assert len(peaks) == 3, peaks
+    for got, want in zip(peaks, (1.09e-8, 4.76e-8, 9.95e-8)):
+        assert abs(np.log(got / want)) < 0.2, peaks
+    # the fit itself: mean over the repetitions against the reference's mean curve
+    np.testing.assert_allclose(res["fitMeasValMean"], g["fitMean"], rtol=0.02)
+
+
+
+@pytest.mark.parametrize("mode", [engine.EXEC_PIPELINE, engine.EXEC_WAVE, engine.EXEC_WORKGROUP])
+def test_device_list_shards_repetitions_like_one_device(mode):
+    """mcsas_problem.n_devices / devices (the repetition loop of mcsas.py:214-262 over several GPUs, inside the C ABI): the
+    same device listed two and three times stands in for two and three GPUs on this one-GPU box — every block runs from
+    its own host thread with its own plan and stream, concurrently — and every array of the result is bit for bit what
+    one device computes for all repetitions (chain id = global repetition index; the pipeline's window geometry does
+    not depend on how many chains share a launch)."""
+    g = load("g4_sphere_q100_fixed.npz")
+    q, I, sig = g["data_q"], g["data_I"], g["data_sigma"]
+    m, _ = make_models("sphere", g["spec_lo"], g["spec_hi"])
+    st = engine.Settings(n_contrib=200, n_reps=7, max_iter=3000, conv_crit=0.5, max_retries=1, seed=11, rep_offset=2, exec_mode=mode)
+    one = engine.analyse(m.setup(), q, I, sig, st)
+    assert len(set(one.num_moves.tolist())) > 3
+    for devs in ((0, 0), (0, 0, 0), (0,) * 9):
+        st2 = engine.Settings(**{**st.__dict__, "devices": devs})
+        many = engine.analyse(m.setup(), q, I, sig, st2)
+        for name in ("contribs", "fit", "chisq", "scaling", "background", "num_iter", "num_moves", "attempts", "converged", "draws"):
+            np.testing.assert_array_equal(getattr(many, name), getattr(one, name), err_msg="%s with %d devices" % (name, len(devs)))
+    # a replayed stream is split along with the repetitions
+    replay = np.stack([g["stream"][k:k + 3300] for k in (0, 50, 100, 150, 200)])
+    st3 = engine.Settings(n_contrib=200, n_reps=5, max_iter=3000, conv_crit=1e-9, max_retries=0, exec_mode=mode)
+    a = engine.analyse(m.setup(), q, I, sig, st3, replay=replay)
+    b = engine.analyse(m.setup(), q, I, sig, engine.Settings(**{**st3.__dict__, "devices": (0, 0)}), replay=replay)
+    np.testing.assert_array_equal(a.contribs, b.contribs); np.testing.assert_array_equal(a.num_moves, b.num_moves)
+    # a device that does not exist fails the whole call, loudly
+    with pytest.raises(mcsas_amd._lib.McSASHipError) as e:
+        engine.analyse(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "devices": (0, 99)}))
+    assert e.value.code == -2
+
+
+def test_mcsas_front_end_takes_a_device_list():
+    g = load("g13_quickstart.npz")
+    out = []
+    for dev in (0, [0, 0, 0]):
+        lo, hi = float(g["lo"]), float(g["hi"])
+        m, _ = make_models("sphere", [lo], [hi])
+        m.radius.histograms().append(mcsas_amd.Histogram(m.radius, lo, hi, binCount=20, xscale='log', yweight='vol'))
+        algo = mcsas_amd.McSAS(seed=3, device=dev, execMode=engine.EXEC_PIPELINE)
+        algo.numContribs.setValue(100); algo.numReps.setValue(5); algo.convergenceCriterion.setValue(20.0)
+        algo.model = m
+        algo.data = mcsas_amd.SASData(g["data_q"], g["data_I"], g["data_sigma"], f_limit=g["data_f_limit"])
+        algo.calc()
+        out.append((algo.result[0]["contribs"].copy(), np.asarray(m.radius.histograms()[0].bins.mean).copy()))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
+
 @pytest.mark.parametrize("waves", [1, 8, 5, -3])
 def test_free_running_philox_matches_oracle(waves):
     """Free-running chains (device Philox) follow the oracle run with the same counter-based stream:
@@ -504,9 +601,11 @@ def test_fromraw_and_series_driver():
     datasets = []
     for radius in (1.0e-8, 2.5e-8):
         _, spec = make_models("sphere", [1e-10], [1e-6])
-        I = O.calc_intensity(spec, q, [radius], 0.6666666)[0] * 1e20 + 1e-3
+        I = O.calc_intensity(spec, q, [radius], 0.6666666)[0]
+        I = I / I.max() + 1e-3                                  # the curve two decades above a flat background
         datasets.append(mcsas_amd.SASData.fromRaw(q, I, None, nBin=50, fuMin=0.02))
-    assert datasets[0].count <= 50 and np.allclose(datasets[0].f.binnedDataU / datasets[0].f.binnedData, 0.02, rtol=0.5)
+    rel = datasets[0].f.binnedDataU / datasets[0].f.binnedData      # the 2 % floor where the curve is smooth, the bin's own scatter
+    assert datasets[0].count <= 50 and np.allclose(rel[:10], 0.02, rtol=0.05) and (rel > 0.015).all()   # where it oscillates
     m = mcsas_amd.Sphere(); m.radius.setActiveRange((2e-9, 1e-7))
     m.radius.histograms().append(mcsas_amd.Histogram(m.radius, 2e-9, 1e-7, binCount=12, xscale='log', yweight='vol'))
     algo = mcsas_amd.McSAS(seed=5)
@@ -518,7 +617,10 @@ def test_fromraw_and_series_driver():
     (uid, rows), = series.items()
     assert uid == ("radius", 2e-9, 1e-7, "vol") and [k for k, _ in rows] == [10.0, 25.0]
     means = [fields[2] for _, fields in rows]                 # Moments.fields: (total, totalStd, mean, ...)
-    assert means[0] < means[1]                               # the larger spheres give the larger mean radius
+    # (a curve that drowns in the background converges at the initial set and both series entries come out identical: the
+    # data sets must really be fitted) — the volume-weighted mean radius tracks the sphere radius of each data set
+    assert all(r["numIter"] > 100 for r in results)
+    assert 0.7e-8 < means[0] < 1.5e-8 and 2.0e-8 < means[1] < 3.2e-8, means
 
 
 def test_kholodenko_regimes_vs_quadpack():
