@@ -106,11 +106,7 @@ typedef struct mcsas_problem {
      * (N draws per active parameter at chain start, then n_active per step; retries continue). */
     uint64_t seed;
     int32_t  rep_offset;         /* global index of this shard's first rep */
-    int32_t  reserved0;          /* 0.  (Measurement builds only: tuning / ablation word of the pipeline mode — bits 8-11 rows per
-                                  * producer wave, 12-15 cap on the scan sub-window / 8, 16 `new` rows stored eagerly with row slots
-                                  * swapped on acceptance (default for rows without an integral: stale rows are evaluated again),
-                                  * 18 Gram operands from HBM/L2 instead of LDS, 19-20 row shares of a SIMD's two producer waves (1 equal, 2 two rows apart), 7 XCD-aware block map; bits 0-6 switch stages OFF and
-                                  * give invalid results.  Tools and tests set it, McSAS never does.) */
+    int32_t  reserved0;          /* must be 0: MCSAS_EINVAL otherwise */
     const double *replay_stream; /* [n_reps][replay_len] or NULL */
     int64_t  replay_len;
 
@@ -243,6 +239,9 @@ int mcsas_hip_rebin(int32_t n, const double *x, const double *f, const double *f
 
 int         mcsas_hip_device_count(void);
 int         mcsas_hip_abi_version(void);
+/* 0: the release library.  1: a measurement build (-DMCSAS_TUNING) in which mcsas_problem.reserved0 selects tuning and
+ * ablation variants of the pipeline mode (csrc/mcsas_hip.hip, mcsas_hip_plan_create); never shipped as libmcsas_hip.so */
+int         mcsas_hip_is_tuning_build(void);
 const char *mcsas_hip_last_error(void);
 
 #ifdef __cplusplus

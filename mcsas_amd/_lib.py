@@ -25,7 +25,7 @@ SYMBOLS = (
     "mcsas_hip_plan_last_ms", "mcsas_hip_plan_total_steps", "mcsas_hip_plan_reseed", "mcsas_hip_plan_info",
     "mcsas_hip_plan_destroy", "mcsas_hip_model_calc", "mcsas_hip_bgfit", "mcsas_hip_observability",
     "mcsas_hip_histogram_prep", "mcsas_hip_prepare_uncertainty", "mcsas_hip_rebin",
-    "mcsas_hip_device_count", "mcsas_hip_abi_version", "mcsas_hip_last_error",
+    "mcsas_hip_device_count", "mcsas_hip_abi_version", "mcsas_hip_is_tuning_build", "mcsas_hip_last_error",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -77,25 +77,32 @@ class McSASHipError(RuntimeError):
         self.code = code
 
 
-_lib = None
+_libs = {}
+TUNING_LIB_PATH = os.environ.get("MCSAS_HIP_TUNING_LIB") or os.path.join(os.path.dirname(LIB_PATH), "libmcsas_hip_tuning.so")
 
 
-def load():
-    """Returns the loaded library; raises if it is not built (no fallback by design)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(tuning=False):
+    """Returns the loaded library; raises if it is not built (no fallback by design).  `tuning`: the measurement build
+    (csrc/Makefile: -DMCSAS_TUNING) in which mcsas_problem.reserved0 selects variants of the pipeline mode — tools and the
+    variant tests only; the release library refuses a non-zero reserved0."""
+    key = bool(tuning)
+    if key in _libs:
+        return _libs[key]
+    path = TUNING_LIB_PATH if tuning else LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
             "mcsas_amd: %s not found. The HIP library is the product path and has no CPU fallback; "
-            "build it with `python __graft_entry__.py build`." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "build it with `python __graft_entry__.py build`." % path)
+    lib = C.CDLL(path)
     missing = [s for s in SYMBOLS if not hasattr(lib, s)]
     if missing:
-        raise ImportError("libmcsas_hip.so lacks symbols: %s" % ", ".join(missing))
+        raise ImportError("%s lacks symbols: %s" % (os.path.basename(path), ", ".join(missing)))
     lib.mcsas_hip_abi_version.restype = C.c_int
     if lib.mcsas_hip_abi_version() != ABI_VERSION:
-        raise ImportError("libmcsas_hip.so ABI %d, binding expects %d" % (lib.mcsas_hip_abi_version(), ABI_VERSION))
+        raise ImportError("%s ABI %d, binding expects %d" % (os.path.basename(path), lib.mcsas_hip_abi_version(), ABI_VERSION))
+    lib.mcsas_hip_is_tuning_build.restype = C.c_int
+    if bool(lib.mcsas_hip_is_tuning_build()) != key and not os.environ.get("MCSAS_HIP_LIB"):
+        raise ImportError("%s: %s build expected" % (os.path.basename(path), "tuning" if tuning else "release"))
     lib.mcsas_hip_last_error.restype = C.c_char_p
     lib.mcsas_hip_device_count.restype = C.c_int
     lib.mcsas_hip_analyse.argtypes = [C.POINTER(Problem), C.POINTER(Result)]
@@ -115,13 +122,13 @@ def load():
     lib.mcsas_hip_histogram_prep.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, _dp, _dp, _dp]
     lib.mcsas_hip_prepare_uncertainty.argtypes = [C.c_int32, _dp, _dp, C.c_double, C.c_int32, _dp]
     lib.mcsas_hip_rebin.argtypes = [C.c_int32, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp, _i32p]
-    _lib = lib
+    _libs[key] = lib
     return lib
 
 
-def check(rc):
+def check(rc, lib=None):
     if rc != 0:
-        raise McSASHipError(rc, load().mcsas_hip_last_error().decode("utf-8", "replace"))
+        raise McSASHipError(rc, (lib or load()).mcsas_hip_last_error().decode("utf-8", "replace"))
 
 
 def as_dp(a):

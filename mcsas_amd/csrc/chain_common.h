@@ -27,6 +27,14 @@ struct ChainOut {
 #define MCSAS_STAMP_ADD(acc, t1, t0) do { } while (0)
 #endif
 
+// The tuning / ablation word (mcsas_problem.reserved0 -> ChainArgs::pad0) exists in measurement builds only
+// (make tuning: -DMCSAS_TUNING); the release library refuses a non-zero word and compiles every use of it to 0.
+#ifdef MCSAS_TUNING
+#define MCSAS_TUNE_BITS(a) ((a).pad0)
+#else
+#define MCSAS_TUNE_BITS(a) 0
+#endif
+
 struct ChainArgs {
     ModelArgs model;
     // data, padded to qpad = 64*QPL entries (pad: q = q[0], w = wI = I = 0)

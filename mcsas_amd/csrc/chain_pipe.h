@@ -45,18 +45,14 @@ namespace mcsas {
 // next step that comes behind this step's sixteen row stores drains them (a memory round trip per row).  The rows are
 // therefore waited for HERE, in front of the stores: everything outstanding at this point was issued before the row was
 // evaluated.  Routing the values through an empty asm pins the wait (and the stores behind it) to this place.
+#define PIPE_TL_WORDS 26                 /* timeline record of a wave: start, end, HW_ID, XCC_ID, then 22 marks */
 #ifdef MCSAS_STAMPS
-#define PIPE_TL_WRITE(pa, t, i) do { if ((pa).timeline && (t) - 1 == (pa).timeline_tick && (threadIdx.x & 63) == 0) (pa).timeline[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 4 + (i)] = wall_clock64(); } while (0)
+#define PIPE_TL_WRITE(pa, t, i) do { if ((pa).timeline && (t) - 1 == (pa).timeline_tick && (threadIdx.x & 63) == 0) (pa).timeline[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * PIPE_TL_WORDS + 4 + (i)] = wall_clock64(); } while (0)
 #else
 #define PIPE_TL_WRITE(pa, t, i) do {} while (0)
 #endif
-#ifdef MCSAS_TLX                         // the four marks show the producer's start-up instead of its phases
-#define PIPE_TLX_MARK(pa, t, i) PIPE_TL_WRITE(pa, t, i)
-#define PIPE_TL_MARK(pa, t, i) do {} while (0)
-#else
-#define PIPE_TLX_MARK(pa, t, i) do {} while (0)
+#define PIPE_TLX_MARK(pa, t, i) PIPE_TL_WRITE(pa, t, 18 + (i))   /* start-up marks 18..21: tables in LDS, proposals prepared, stale rows refreshed, row loop */
 #define PIPE_TL_MARK(pa, t, i) PIPE_TL_WRITE(pa, t, i)
-#endif
 #define PIPE_PIN_ROW(arr) do { _Pragma("unroll") for (int j_ = 0; j_ < QPL; ++j_) asm volatile("" : "+v"(arr[j_])); } while (0)
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -91,7 +87,9 @@ struct PipeGeom {
     int32_t sub_per_block;        // scan sub-windows per producer block (8 * rows_per_wave / w)
     int32_t lazy_rows;            // no `new` rows are stored: an accepted step marks its contribution's cached row stale and the producer that
                                   // next needs it as `old` evaluates it again from the parameter set (rows without an integral only)
-    int32_t overlap;              // producer: rows without an integral — the Gram MFMAs of sub-window s are issued between the rows of s + 1
+    int32_t overlap;              // producer variant (tuning): the Gram MFMAs of sub-window s are issued between the rows of s + 1, operands from HBM/L2
+    int32_t gram_lds;             // producer: the sub-window's d rows are also kept in LDS and the Gram MFMAs read them from there
+    int32_t drow_off;             // producer LDS: offset (doubles) of those rows, row stride qpad + PIPE_DROW_PAD
     int32_t pad_g;
     uint64_t prod_lds, scan_lds;
 };
@@ -141,6 +139,7 @@ __device__ __forceinline__ void store_snap(PipeSnap *p, const PipeSnap &s) {
 constexpr int PIPE_BLOCK = 512;      // threads per workgroup of the tick kernel (8 waves)
 constexpr int PIPE_WAVES = PIPE_BLOCK / 64;
 constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;
+constexpr int PIPE_DROW_PAD = 8;         // LDS d rows: stride qpad + 8 doubles, so that the 64 16-byte operands of one Gram load hit 64 different bank groups
 constexpr int PIPE_GRAM_NT_MAX = 3;          // overlapped producer: tiles per sub-window — W <= 32 (two 16-row groups: 3 tiles) or 24 packed (2)
 constexpr int PIPE_MAX_ROW_DOUBLES = 32;   // scan block: doubles per lane held in row registers (rows per wave and sub-window x q per lane)   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
@@ -161,7 +160,7 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     // whose d rows fit the scan block's LDS row buffer (the accepted rows are applied to ft from there, not from HBM).
     // Rows without an integral run the overlapped producer (Gram of sub-window s between the rows of s + 1), whose tile
     // schemes cover W <= 32.
-    const bool overlap = !heavy_rows && !gram_global_req;
+    const bool overlap = !heavy_rows && gram_global_req;
     auto pick_w = [&](int r) {
         int w = 8;
         for (int ws = 8; ws <= 8 * r && ws <= (overlap ? 32 : 64); ws += 8) {
@@ -237,8 +236,15 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         const size_t red = overlap ? (size_t)2 * PIPE_WAVES * PIPE_GRAM_NT_MAX * 256 : (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256;
         g->prod_lds = sizeof(double) * ((size_t)g->gram_off + 16 + red);    // 16 doubles: counters
         g->overlap = overlap ? 1 : 0; g->pad_g = 0;
+        // Rows without an integral: the Gram phase is a third of the producer's tick; with the sub-window's d rows parked
+        // in LDS on their way to HBM it is MFMA-bound instead of waiting for an L2 round trip per sub-window.
+        g->gram_lds = 0; g->drow_off = 0;
+        const size_t with_rows = g->prod_lds + sizeof(double) * (size_t)g->w * (qpad + PIPE_DROW_PAD);
+        if (!heavy_rows && !overlap && with_rows <= 160 * 1024) {
+            g->gram_lds = 1; g->drow_off = g->gram_off + 16 + (int)red; g->prod_lds = with_rows;
+        }
         // ... and no `new` rows go to HBM either (4 KB per step at Q = 512, a fifth of the tick's memory traffic): see lazy_rows
-        g->lazy_rows = (overlap && !eager_req) ? 1 : 0;
+        g->lazy_rows = ((g->gram_lds || overlap) && !eager_req) ? 1 : 0;
     }
     g->scan_waves = PIPE_WAVES;
     // scan block LDS: the sub-window's d rows, two Gram blocks (double buffer), ft and w*ft, the window's scalars, h of
@@ -352,7 +358,7 @@ __device__ __forceinline__ void pipe_gram_mfma(const MCSAS_GLOBAL double *drows,
 
 // tile number -> (row group, column group) of the upper triangle, and the store of one summed element
 template <int T>
-__device__ __forceinline__ void pipe_gram_store(int tsel, int idx, double sum, int W, MCSAS_GLOBAL double *gout) {
+__device__ __forceinline__ void pipe_gram_store(int tsel, int idx, double sum, int W, MCSAS_GLOBAL double *gout, MCSAS_GLOBAL double *scal_sub = nullptr) {
     int ti = 0, tgi = 0, tgj = 0;
 #pragma unroll
     for (int gi = 0; gi < T; ++gi)
@@ -360,7 +366,10 @@ __device__ __forceinline__ void pipe_gram_store(int tsel, int idx, double sum, i
         for (int gj = gi; gj < T; ++gj) { if (ti == tsel) { tgi = gi; tgj = gj; } ++ti; }
     const int i = 4 * (idx >> 6) + ((idx & 63) >> 4), j = idx & 15;   // result register r of lane l holds D[4 r + l / 16][l % 16]
     const int ar = 16 * tgi + i, kc = 16 * tgj + j;
-    if (ar < W && kc < W) gout[(size_t)ar * W + kc] = sum;
+    if (ar < W && kc < W) {
+        gout[(size_t)ar * W + kc] = sum;
+        if (scal_sub && ar == kc) scal_sub[ar * 4 + 2] = sum;
+    }
 }
 
 // All eight waves of the block, partial tiles summed in wave order through LDS between two barriers.
@@ -405,6 +414,118 @@ __device__ __forceinline__ void pipe_prod_gram(const MCSAS_GLOBAL double *drows,
         case 2: pipe_prod_gram_t<QPL, 2>(drows, qpad, W, nvalid, lw, gred, gout); break;
         case 3: pipe_prod_gram_t<QPL, 3>(drows, qpad, W, nvalid, lw, gred, gout); break;
         default: pipe_prod_gram_t<QPL, 4>(drows, qpad, W, nvalid, lw, gred, gout); break;
+    }
+}
+
+
+// The same Gram block with the operands read from the LDS copy of the sub-window's d rows (row stride dstr).
+// PACK (W = 24, three 8-row groups g0 g1 g2): the six upper-triangular 8x8 blocks fit TWO 16x16 tiles instead of the
+// three of the 16-row grouping — tile 0 = rows [g0 g1] x columns [g1 g2] (blocks 01 02 11 12), tile 1 = rows and
+// columns [g0 g2] (blocks 00 22; its 02 is a duplicate and not stored): a third fewer MFMAs.
+template <int QPL, int T, bool PACK>
+__device__ __forceinline__ void pipe_gram_mfma_lds(const double *drows, int dstr, int nvalid, const double *lw, int gw,
+                                                   v4f64 (&acc)[PACK ? 2 : T * (T + 1) / 2]) {
+    const int lane = threadIdx.x & 63;
+    const int m = lane & 15, kk = lane >> 4;
+    constexpr int NT = PACK ? 2 : T * (T + 1) / 2;
+    constexpr int NL = PACK ? 3 : T;                          // row operands per lane and step-pair
+    constexpr int SLICE = 64 * QPL / PIPE_WAVES;
+    static_assert(SLICE >= 8, "too many waves for this q count");
+    const int qs = gw * SLICE + kk * 2;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = (v4f64){0., 0., 0., 0.};
+    const double *rowp[NL];
+    bool rowok[NL];
+#pragma unroll
+    for (int gi = 0; gi < NL; ++gi) {
+        const int rr = PACK ? (gi == 0 ? m : gi == 1 ? 8 + m : (m < 8 ? m : m + 8)) : 16 * gi + m;
+        rowok[gi] = rr < nvalid;
+        rowp[gi] = drows + (size_t)(rowok[gi] ? rr : 0) * dstr + qs;
+    }
+#pragma unroll
+    for (int sp = 0; sp < SLICE / 8; ++sp) {
+        v2f64 av[NL], bv[NL];
+        const v2f64 wv = *reinterpret_cast<const v2f64 *>(lw + qs + 8 * sp);
+#pragma unroll
+        for (int gi = 0; gi < NL; ++gi) {
+            const v2f64 x = *reinterpret_cast<const v2f64 *>(rowp[gi] + 8 * sp);
+            av[gi] = rowok[gi] ? x : (v2f64){0., 0.};
+            bv[gi] = av[gi] * wv;
+        }
+        if constexpr (PACK) {
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0].x, bv[1].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2].x, bv[2].x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0].y, bv[1].y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2].y, bv[2].y, acc[1], 0, 0, 0);
+        } else {
+            int ti = 0;
+#pragma unroll
+            for (int gi = 0; gi < T; ++gi)
+#pragma unroll
+                for (int gj = gi; gj < T; ++gj) {
+                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].x, bv[gj].x, acc[ti], 0, 0, 0);
+                    acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[gi].y, bv[gj].y, acc[ti], 0, 0, 0);
+                    ++ti;
+                }
+        }
+    }
+}
+
+// element idx of packed tile tsel -> (row, column) of the 24-step sub-window, or skipped
+// (the block's diagonal, g_k = sum_q w d_k^2, is the third of a step's ft-independent sums: to scal_sub[k][2])
+__device__ __forceinline__ void pipe_gram_store_pack(int tsel, int idx, double sum, MCSAS_GLOBAL double *gout, MCSAS_GLOBAL double *scal_sub) {
+    const int i = 4 * (idx >> 6) + ((idx & 63) >> 4), j = idx & 15;
+    if (tsel == 0) {
+        gout[(size_t)i * 24 + 8 + j] = sum;
+        if (i == 8 + j) scal_sub[i * 4 + 2] = sum;
+    } else if ((i < 8) == (j < 8)) {
+        const int ar = i < 8 ? i : i + 8, kc = j < 8 ? j : j + 8;
+        gout[(size_t)ar * 24 + kc] = sum;
+        if (ar == kc) scal_sub[ar * 4 + 2] = sum;
+    }
+}
+
+template <int QPL, int T, bool PACK>
+__device__ __forceinline__ void pipe_prod_gram_lds_t(const double *drows, int dstr, int W, int nvalid, const double *lw,
+                                                     double *gred, MCSAS_GLOBAL double *gout, MCSAS_GLOBAL double *scal_sub) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NT = PACK ? 2 : T * (T + 1) / 2;
+    v4f64 acc[NT];
+    pipe_gram_mfma_lds<QPL, T, PACK>(drows, dstr, nvalid, lw, wave, acc);
+    constexpr int TPR = PIPE_GRAM_TILES_PER_ROUND;
+#pragma unroll
+    for (int r0 = 0; r0 < NT; r0 += TPR) {
+#pragma unroll
+        for (int u = 0; u < TPR; ++u)
+            if (r0 + u < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gred[((size_t)(wave * TPR + u) * 4 + r) * 64 + lane] = acc[r0 + u < NT ? r0 + u : 0][r];
+            }
+        PIPE_LDS_BARRIER();
+        {
+            const int u = tid >> 8, idx = tid & 255;
+            const int tsel = r0 + u;
+            if (tsel < NT) {
+                double sum = 0.;
+#pragma unroll
+                for (int v = 0; v < PIPE_WAVES; ++v) sum += gred[(size_t)(v * TPR + u) * 256 + idx];
+                if constexpr (PACK) pipe_gram_store_pack(tsel, idx, sum, gout, scal_sub);
+                else pipe_gram_store<T>(tsel, idx, sum, W, gout, scal_sub);
+            }
+        }
+        if (r0 + TPR < NT) PIPE_LDS_BARRIER();
+    }
+}
+
+template <int QPL>
+__device__ __forceinline__ void pipe_prod_gram_lds(const double *drows, int dstr, int W, int nvalid, const double *lw,
+                                                   double *gred, MCSAS_GLOBAL double *gout, MCSAS_GLOBAL double *scal_sub) {
+    if (W == 24) { pipe_prod_gram_lds_t<QPL, 2, true>(drows, dstr, W, nvalid, lw, gred, gout, scal_sub); return; }
+    switch ((W + 15) >> 4) {                                   // uniform for the launch
+        case 1: pipe_prod_gram_lds_t<QPL, 1, false>(drows, dstr, W, nvalid, lw, gred, gout, scal_sub); break;
+        case 2: pipe_prod_gram_lds_t<QPL, 2, false>(drows, dstr, W, nvalid, lw, gred, gout, scal_sub); break;
+        case 3: pipe_prod_gram_lds_t<QPL, 3, false>(drows, dstr, W, nvalid, lw, gred, gout, scal_sub); break;
+        default: pipe_prod_gram_lds_t<QPL, 4, false>(drows, dstr, W, nvalid, lw, gred, gout, scal_sub); break;
     }
 }
 
@@ -675,8 +796,8 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         return;
     }
 
-    if (a.pad0 & 16) return;                                  // diagnostic: no window rows
-    if constexpr (pipe_light_model(M)) if (pa.g.overlap) {         // (rows with an integral never take this path: not instantiated for them)
+    if (MCSAS_TUNE_BITS(a) & 16) return;                                  // diagnostic: no window rows
+    if constexpr (pipe_light_model(M)) if (pa.g.overlap || pa.g.gram_lds) {   // (rows with an integral never take this path: not instantiated for them)
         // ---- overlapped producer.  The block's rows are nsb sub-windows of W; phase ss = the rows of sub-window ss, every
         // wave its share, d = new - old straight to the window buffer.  The Gram block of sub-window ss - 1 is worked off
         // in units BETWEEN the rows of phase ss (matrix pipe beside the vector pipe: while one wave of a SIMD is inside a run
@@ -689,7 +810,12 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         const int W = pa.g.w, nsb = pa.g.sub_per_block, BR = nsb * W;
         // Rows per wave and sub-window: W / 8 on average; tuning bits 19-20 shift rows from the four waves that share
         // their SIMDs with an older wave (4-7) to the older ones (0-3): 0 = equal shares, 1 / 2 = one / two rows.
-        const int rw_even = W >> 3, skew_req = (a.pad0 >> 19) & 3, skew = skew_req < rw_even ? skew_req : rw_even - 1;
+        // (the LDS variant's default is one row: the SIMD arbitrates oldest-first, so with equal shares the older wave is done
+        // early and the younger one finishes the phase alone, latency-bound — measured 4 + 2 rows 3.92 ms, 3 + 3 4.03, 5 + 1 4.2;
+        // bits 19-20 = 3 there: equal shares)
+        const int rw_even = W >> 3, skew_bits = (MCSAS_TUNE_BITS(a) >> 19) & 3;
+        const int skew_req = pa.g.gram_lds ? (skew_bits == 0 ? 1 : (skew_bits == 3 ? 0 : skew_bits)) : skew_bits;
+        const int skew = skew_req < rw_even ? skew_req : rw_even - 1;
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const int RW = wv < 4 ? rw_even + skew : rw_even - skew;                        // my rows per sub-window
         const int rbase = wv < 4 ? wv * (rw_even + skew) : 4 * (rw_even + skew) + (wv - 4) * (rw_even - skew);   // my first row in a sub-window
@@ -704,7 +830,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         double *gred = lds + pa.g.gram_off + 16;                                       // [2][8 waves][PIPE_GRAM_NT_MAX][256]
         constexpr size_t GRED = (size_t)PIPE_WAVES * PIPE_GRAM_NT_MAX * 256;
         const int nmine = nsb * RW;                                                    // my rows (<= 8), lane l <-> my l-th row
-        const bool no_gram = a.pad0 & 64;                                              // diagnostic: no Gram blocks (uniform)
+        const bool no_gram = MCSAS_TUNE_BITS(a) & 64;                                              // diagnostic: no Gram blocks (uniform)
         const int lrow = (lane / RW) * W + rbase + (lane % RW);                        // its offset in the block
         const bool lazy = pa.g.lazy_rows;
         PIPE_TLX_MARK(pa, t, 0);
@@ -791,12 +917,75 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
             for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) if (p < P) pval[k * MCSAS_MAX_ACTIVE + p] = prow[p];
             povf[k] = pov;
         }
-        const int ntiles = pipe_gram_tiles(W);
-        constexpr int UN = QPL;                                   // Gram units (8 q each) of my q slice
         auto nvalid_of = [&](int ss) {
             const int64_t left = max_iter - (w * Kb + (int64_t)(by * nsb + ss) * W);
             return left >= W ? W : (left > 0 ? (int)left : 0);
         };
+        if (pa.g.gram_lds) {
+            // ---- default: sub-window by sub-window — every wave evaluates its rows of the sub-window (d also into the LDS row
+            // buffer), barrier, the eight waves take the Gram block from LDS, next sub-window.  Only the LDS traffic is waited
+            // for at the barriers: the rows' global stores drain behind the MFMAs.
+            const int dstr = qpad + PIPE_DROW_PAD;
+            double *dbuf = lds + pa.g.drow_off;
+            double ocur[QPL], onext[QPL];
+            {
+                const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
+            }
+            PIPE_PIN_ROW(ocur);                                   // (a pending load carried into the loop would be waited for at its head, every iteration)
+            for (int ss = 0; ss < nsb; ++ss) {
+                for (int jr = 0; jr < RW; ++jr) {
+                    const int l = ss * RW + jr, bl = __builtin_amdgcn_readfirstlane(l);
+                    const int kl = ss * W + rbase + jr, k = by * BR + kl;
+                    const Contrib<M> cnew = prop.bcast(bl);
+                    const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
+                    double d[QPL], nwv[QPL];
+                    {
+                        const int bn = __builtin_amdgcn_readfirstlane(l + 1 < nmine ? l + 1 : l);
+                        const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bn) * qpad + lane;
+#pragma unroll
+                        for (int j = 0; j < QPL; ++j) onext[j] = orow[WAVE * j];
+                    }
+                    // (a row behind max_iter — the last window of a run only — is evaluated like any other: its proposal is the
+                    // generators' midpoint, its stores land in slots nobody reads, the Gram block masks it)
+                    const auto nrow = cache + (size_t)sslot * qpad + lane;
+                    const auto dr = dwin + (size_t)k * qpad + lane;
+                    double *dl = dbuf + (size_t)(rbase + jr) * dstr + lane;
+                    RowEval<M, QPL>::run(cnew, qt, lane, nwv);
+                    PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
+                    double s1 = 0., s2 = 0.;
+#pragma unroll
+                    for (int j = 0; j < QPL; ++j) {
+                        const int iq = lane + WAVE * j;
+                        if (!lazy) nrow[WAVE * j] = nwv[j];
+                        d[j] = nwv[j] - ocur[j];
+                        dr[WAVE * j] = d[j];
+                        dl[WAVE * j] = d[j];
+                        s1 = fma(lw[iq], d[j], s1); s2 = fma(lwI[iq], d[j], s2);
+                    }
+                    // a = sum w d (even lanes), e = sum wI d (odd lanes); g = sum w d^2 is the Gram block's diagonal
+                    const double ae = wave_sum2_split(s1, s2, lane);
+                    if (lane < 2) scal[(size_t)k * 4 + lane] = ae;
+#pragma unroll
+                    for (int j = 0; j < QPL; ++j) ocur[j] = onext[j];
+                }
+                PIPE_TL_MARK(pa, t, 2 * (ss < 4 ? ss : 3));
+                if (!no_gram) PIPE_LDS_BARRIER();                 // the sub-window's rows are in LDS
+                const int nvalid = nvalid_of(ss);
+                if (nvalid > 0 && !no_gram)                       // uniform in the block
+                    pipe_prod_gram_lds<QPL>(dbuf, dstr, W, nvalid, lw, gred, gwin + (size_t)(by * nsb + ss) * W * W,
+                                            scal + (size_t)(by * BR + ss * W) * 4);
+                // (the next sub-window's rows overwrite dbuf only behind the reduction's first barrier, which every wave
+                // passes after its last operand read; gred is written again behind the next rows -> Gram barrier)
+                PIPE_TL_MARK(pa, t, 2 * (ss < 4 ? ss : 3) + 1);
+            }
+            PIPE_TL_MARK(pa, t, 17);
+            return;
+        }
+#ifdef MCSAS_TUNING                                           // the overlapped variant (pipe_geometry: bit 18) is a measurement build's
+        const int ntiles = pipe_gram_tiles(W);
+        constexpr int UN = QPL;                                   // Gram units (8 q each) of my q slice
         // the tile scheme is uniform for the launch; everything below is compiled once per scheme
         auto rows_and_gram = [&](auto scheme_t, auto scheme_pack) {
             constexpr int T = decltype(scheme_t)::value;
@@ -856,6 +1045,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                     // a = sum w d (even lanes), e = sum wI d (odd lanes); g = sum w d^2 is the Gram block's diagonal
                     const double ae = wave_sum2_split(s1, s2, lane);
                     if (lane < 2) scal[(size_t)k * 4 + lane] = ae;
+                    PIPE_TL_MARK(pa, t, (ss < 2 ? ss : 1) * 4 + (jr < 3 ? jr : 3));
                     if (ss > 0 && !no_gram && jr == 0) {
                         // B(ss - 1): my stores of phase ss - 1 are older than this row's QPL (or more) stores
                         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QPL < 8 ? QPL : 8) : "memory");
@@ -869,12 +1059,14 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                         }
                     }
                 }
-                PIPE_TL_MARK(pa, t, ss < 3 ? ss : 3);
+                PIPE_TL_MARK(pa, t, 8 + (ss < 3 ? ss : 3));
             }
             // ---- the tail: block nsb - 2 is summed, the last sub-window's Gram block has nothing to run beside
             if (!no_gram) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PIPE_TL_MARK(pa, t, 12);
                 PIPE_LDS_BARRIER();                                   // B(nsb - 1)
+                PIPE_TL_MARK(pa, t, 13);
                 if (nsb > 1 && nvalid_of(nsb - 2) > 0)
                     pipe_gram_sum_store(W, gred + (size_t)((nsb - 2) & 1) * GRED, gwin + (size_t)(by * nsb + nsb - 2) * W * W,
                                         scal + (size_t)(by * BR + (nsb - 2) * W) * 4);
@@ -883,6 +1075,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                     const auto dlast = dwin + (size_t)(by * BR + (nsb - 1) * W) * qpad;
                     // batches of UCAP units, the next batch's operands requested before this one's MFMAs
                     v2f64 G2[PIPE_GRAM_PREF];
+                    PIPE_TL_MARK(pa, t, 14);
                     pipe_gram_fetch<QPL, T, PACK>(dlast, qpad, nv, wv, 0, UN < UCAP ? UN : UCAP, G);
                     for (int u = 0; u < UN; u += 2 * UCAP) {
                         const int n0 = UN - u < UCAP ? UN - u : UCAP;
@@ -893,8 +1086,10 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                         if (n2 > 0) pipe_gram_fetch<QPL, T, PACK>(dlast, qpad, nv, wv, u2, n2, G);
                         if (n1 > 0) pipe_gram_consume<QPL, T, PACK>(G2, nv, lw, wv, un, n1, gacc);
                     }
+                    PIPE_TL_MARK(pa, t, 15);
                     pipe_gram_park(gacc, ntiles, gred + (size_t)((nsb - 1) & 1) * GRED, wv, lane);
                     PIPE_LDS_BARRIER();
+                    PIPE_TL_MARK(pa, t, 16);
                     pipe_gram_sum_store(W, gred + (size_t)((nsb - 1) & 1) * GRED, gwin + (size_t)(by * nsb + nsb - 1) * W * W,
                                         scal + (size_t)(by * BR + (nsb - 1) * W) * 4);
                 }
@@ -903,7 +1098,8 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         if (W == 24) rows_and_gram(std::integral_constant<int, 2>{}, std::integral_constant<bool, true>{});
         else if (W <= 16) rows_and_gram(std::integral_constant<int, 1>{}, std::integral_constant<bool, false>{});
         else rows_and_gram(std::integral_constant<int, 2>{}, std::integral_constant<bool, false>{});
-        PIPE_TL_MARK(pa, t, 3);
+#endif
+        PIPE_TL_MARK(pa, t, 17);
         return;
     }
 
@@ -999,7 +1195,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     }
     // ---- the sub-window's Gram block from the d rows the block has just written (workgroup-scope visibility:
     // the barrier's fence; same CU, same L1)
-    if (a.pad0 & 64) return;                                  // diagnostic: no Gram blocks
+    if (MCSAS_TUNE_BITS(a) & 64) return;                                  // diagnostic: no Gram blocks
     MCSAS_STAMP(pp1);
     PIPE_TL_MARK(pa, t, 0);
     __syncthreads();
@@ -1189,7 +1385,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         MCSAS_IN_VGPR(cSII); MCSAS_IN_VGPR(cSI); MCSAS_IN_VGPR(cScen); MCSAS_IN_VGPR(cSIoSw); MCSAS_IN_VGPR(cinvSw);
         MCSAS_IN_VGPR(cCrit); MCSAS_IN_VGPR(cnq);
         MCSAS_IN_VGPR(SC); MCSAS_IN_VGPR(SIC); MCSAS_IN_VGPR(SCC); MCSAS_IN_VGPR(X);
-        const bool find_bg = a.find_bg, pos_bg = a.pos_bg, never_accept = a.pad0 & 32;
+        const bool find_bg = a.find_bg, pos_bg = a.pos_bg, never_accept = MCSAS_TUNE_BITS(a) & 32;
 #ifdef MCSAS_STAMPS
         int64_t ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1465,7 +1661,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
     struct Timeline {                                          // one record per wave, written when the wave leaves the kernel
         uint64_t *p, t0; uint32_t hw;
         __device__ Timeline(const PipeArgs &pa, int tick) {
-            p = (pa.timeline && tick == pa.timeline_tick && (threadIdx.x & 63) == 0) ? pa.timeline + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 : nullptr;
+            p = (pa.timeline && tick == pa.timeline_tick && (threadIdx.x & 63) == 0) ? pa.timeline + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * PIPE_TL_WORDS : nullptr;
             t0 = wall_clock64();
             hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
         }
@@ -1490,7 +1686,7 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
         // 32 CUs with one block per CU — two XCDs get 35 blocks and their chains take two rounds.
         const int gy = hot.prod_blocks_y;
         int rep = (b - R) / gy, y = (b - R) % gy;
-        if (pa.c.pad0 & 128) { const int x = b & 7, j = (b - R) >> 3; rep = x + 8 * (j / gy); y = j % gy; }
+        if (MCSAS_TUNE_BITS(pa.c) & 128) { const int x = b & 7, j = (b - R) >> 3; rep = x + 8 * (j / gy); y = j % gy; }
         if (rep < R) pipe_prod_block<M, QPL>(pa, hot, lds, rep, y, gy, t + 1);
     }
 }

@@ -158,7 +158,7 @@ __device__ __forceinline__ void wg_producer(const ChainArgs &a, const WgGeom &g,
         int pov = 0;
         for (int64_t win = 0;; ++win) {
             const int buf = (int)(win & 1);
-            if (chain_runs && !(a.pad0 & 1)) {
+            if (chain_runs && !(MCSAS_TUNE_BITS(a) & 1)) {
                 for (int jj = 0; jj < rpw; ++jj) {
                     const int k = (wave - 1) + NP * jj;
                     const int64_t s = win * K + k;
@@ -296,7 +296,7 @@ __device__ __forceinline__ void wg_scanner(const ChainArgs &a, const WgGeom &g, 
                 const double *sbase = sh.scal + (size_t)sb * K * 4;
                 int k = 0;
                 if (!(cur.chi2 > a.conv_crit) || stopped) k = kmax;      // nothing to do
-                if (a.pad0 & 2) { num_iter += kmax - k; k = kmax; }       // diagnostic: skip the scan
+                if (MCSAS_TUNE_BITS(a) & 2) { num_iter += kmax - k; k = kmax; }       // diagnostic: skip the scan
                 // Steps are decided EIGHT at a time: h_g = Σ (w·ft)·d_g for the next eight steps is
                 // valid for all of them as long as none is accepted (the usual case); lane g of every
                 // octet then evaluates step g's decision.  The first accepted step (if any) is applied

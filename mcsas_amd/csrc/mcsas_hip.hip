@@ -416,6 +416,9 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     *out = nullptr;
     if (p->struct_size != sizeof(mcsas_problem))
         return fail(MCSAS_EINVAL, "mcsas_problem size %u, library expects %zu (ABI mismatch)", p->struct_size, sizeof(mcsas_problem));
+#ifndef MCSAS_TUNING
+    if (p->reserved0 != 0) return fail(MCSAS_EINVAL, "mcsas_problem.reserved0 must be 0 (it is %d)", p->reserved0);
+#endif
     if (p->nq < 1 || !p->q || !p->intensity || !p->sigma) return fail(MCSAS_EINVAL, "nq/q/intensity/sigma missing");
     if (p->n_contrib < 1 || p->n_reps < 1) return fail(MCSAS_EINVAL, "n_contrib and n_reps must be >= 1");
     if (p->n_active < 1) return fail(MCSAS_EINVAL, "a plan needs an active parameter (mcsas_hip_analyse answers the no-active-parameter case itself)");
@@ -461,10 +464,17 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     const bool heavy_rows = tab_shared > 0 || margs.smear_nk > 0;
     int n_cus = 256;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, pl->dev) == hipSuccess && v > 0) n_cus = v; }
-    const int rpw_req = (p->reserved0 >> 8) & 15;          // tuning / diagnostics: rows per producer wave of the pipeline, 0 = automatic
-    const int eager_req = (p->reserved0 >> 16) & 1;        // tuning: 1 = every proposal's `new` row is stored and row slots are swapped on acceptance (no lazy re-evaluation)
-    const int gram_global_req = (p->reserved0 >> 18) & 1;  // tuning: 1 = Gram operands from the d rows in HBM/L2 (no LDS copy of the sub-window)
-    const int sub_req = (p->reserved0 >> 12) & 15;         // tuning: cap on the scan sub-window, in units of 8 steps (0 = automatic)
+#ifdef MCSAS_TUNING
+    // measurement build (make tuning): mcsas_problem.reserved0 is the tuning / ablation word of the pipeline mode —
+    // bits 8-11 rows per producer wave (0 = automatic), 12-15 cap on the scan sub-window in units of 8 steps, 16 every
+    // proposal's `new` row stored and row slots swapped on acceptance (no lazy re-evaluation of stale rows), 18 the overlapped
+    // producer (Gram MFMAs of sub-window s between the rows of s + 1, operands from HBM/L2), 19-20 row shares of a SIMD's two
+    // producer waves, 7 XCD-aware block map; bits 0-6 switch stages OFF and give invalid results
+    const int rpw_req = (p->reserved0 >> 8) & 15, eager_req = (p->reserved0 >> 16) & 1, gram_global_req = (p->reserved0 >> 18) & 1,
+              sub_req = (p->reserved0 >> 12) & 15;
+#else
+    const int rpw_req = 0, eager_req = 0, gram_global_req = 0, sub_req = 0;
+#endif
 #define TABD(waves_per_block) (tab_shared + (waves_per_block) * tab_row)
     // execution mode (results do not depend on it)
     int mode = p->exec_mode;
@@ -569,7 +579,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         a.gen_lo[c] = p->gen_lo[c]; a.gen_hi[c] = p->gen_hi[c]; a.start_value[c] = p->start_value[c];
         a.gen_kind[c] = p->gen_kind[c];
     }
-    a.seed = p->seed; a.rep_offset = p->rep_offset; a.pad0 = p->reserved0;   // reserved0: diagnostic role ablation
+    a.seed = p->seed; a.rep_offset = p->rep_offset; a.pad0 = p->reserved0;   // (0 in the release library: checked above)
     a.replay = pl->d_replay; a.replay_len = p->replay_len;
     a.stop_flag = d_stop;
     a.rset = pl->d_rset; a.cache = pl->d_cache; a.cache_rows = cache_rows; a.fit = pl->d_fit; a.out = pl->d_out;
@@ -608,8 +618,8 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
 #ifdef MCSAS_STAMPS
         if (const char *e = getenv("MCSAS_TIMELINE_TICK")) {
             pa.timeline_tick = atoi(e);
-            PCHK(hipMalloc(&pl->d_timeline, sizeof(uint64_t) * 8 * 8 * (R + R * pa.g.prod_blocks_y)));
-            PCHK(hipMemset(pl->d_timeline, 0, sizeof(uint64_t) * 8 * 8 * (R + R * pa.g.prod_blocks_y)));
+            PCHK(hipMalloc(&pl->d_timeline, sizeof(uint64_t) * 8 * PIPE_TL_WORDS * (R + R * pa.g.prod_blocks_y)));
+            PCHK(hipMemset(pl->d_timeline, 0, sizeof(uint64_t) * 8 * PIPE_TL_WORDS * (R + R * pa.g.prod_blocks_y)));
             pa.timeline = pl->d_timeline;
         }
 #endif
@@ -652,7 +662,7 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     const long long attempts = (long long)pl->prob.max_retries + 1;
     const long long max_ticks = (win_per_attempt >= TICK_CAP / attempts) ? TICK_CAP : std::min(attempts * win_per_attempt + 4, TICK_CAP);
     // scan blocks + producer blocks (chain-major; 8 XCD classes of ceil(R/8) chains each with diagnostic bit 128)
-    const dim3 grid((pl->args.pad0 & 128) ? R + 8 * ((R + 7) / 8) * pa.g.prod_blocks_y : R + R * pa.g.prod_blocks_y);
+    const dim3 grid((MCSAS_TUNE_BITS(pl->args) & 128) ? R + 8 * ((R + 7) / 8) * pa.g.prod_blocks_y : R + R * pa.g.prod_blocks_y);
     PipeHot hot{};
     hot.q = pa.c.q; hot.w = pa.c.w; hot.wI = pa.c.wI; hot.chains = pa.chains;
     hot.n_reps = pa.c.n_reps; hot.n_contrib = pa.c.n_contrib; hot.n_active = pa.c.model.n_active; hot.qpad = pa.c.qpad;
@@ -752,16 +762,17 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
         }
         if (pl->d_timeline) {
             const size_t nb = R + R * pl->pipe.g.prod_blocks_y;
-            std::vector<uint64_t> tl(nb * 8 * 8);
+            std::vector<uint64_t> tl(nb * 8 * PIPE_TL_WORDS);
             HIPCHK(hipMemcpy(tl.data(), pl->d_timeline, tl.size() * 8, hipMemcpyDeviceToHost));
             uint64_t t0 = ~0ull;
-            for (size_t i = 0; i < nb * 8; ++i) if (tl[i * 8] && tl[i * 8] < t0) t0 = tl[i * 8];
+            const size_t TW = PIPE_TL_WORDS;
+            for (size_t i = 0; i < nb * 8; ++i) if (tl[i * TW] && tl[i * TW] < t0) t0 = tl[i * TW];
             fprintf(stderr, "[mcsas timeline] tick %d: block wave start_us end_us hw_id xcc\n", pl->pipe.timeline_tick);
             for (size_t i = 0; i < nb * 8; ++i)
-                if (tl[i * 8]) {
-                    fprintf(stderr, "[mcsas timeline] %zu %zu %.2f %.2f %llx %llu", i / 8, i % 8, (tl[i * 8] - t0) * 0.01, (tl[i * 8 + 1] - t0) * 0.01,
-                            (unsigned long long)tl[i * 8 + 2], (unsigned long long)tl[i * 8 + 3]);
-                    for (int m = 4; m < 8; ++m) fprintf(stderr, " %.2f", tl[i * 8 + m] ? (tl[i * 8 + m] - t0) * 0.01 : 0.0);
+                if (tl[i * TW]) {
+                    fprintf(stderr, "[mcsas timeline] %zu %zu %.2f %.2f %llx %llu", i / 8, i % 8, (tl[i * TW] - t0) * 0.01, (tl[i * TW + 1] - t0) * 0.01,
+                            (unsigned long long)tl[i * TW + 2], (unsigned long long)tl[i * TW + 3]);
+                    for (size_t m = 4; m < TW; ++m) fprintf(stderr, " %.2f", tl[i * TW + m] ? (tl[i * TW + m] - t0) * 0.01 : 0.0);
                     fprintf(stderr, "\n");
                 }
         }
@@ -1130,4 +1141,11 @@ extern "C" int mcsas_hip_device_count(void) {
     return n;
 }
 extern "C" int mcsas_hip_abi_version(void) { return MCSAS_ABI_VERSION; }
+extern "C" int mcsas_hip_is_tuning_build(void) {
+#ifdef MCSAS_TUNING
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" const char *mcsas_hip_last_error(void) { return g_err.c_str(); }

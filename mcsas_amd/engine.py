@@ -61,7 +61,7 @@ class Settings:
     waves_per_chain: int = 0
     cache_intensities: int = -1
     exec_mode: int = 0                 # MCSAS_EXEC_*: 0 auto, 1 wave, 2 workgroup, 3 pipeline
-    debug_flags: int = 0               # diagnostic only (role ablation in the workgroup kernel)
+    debug_flags: int = 0               # tuning / ablation word: non-zero runs on the measurement build (libmcsas_hip_tuning.so)
 
 
 def _fill(arr, values, n):
@@ -160,10 +160,10 @@ class ChainResults:
 
 def analyse(model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None, smear=None) -> ChainResults:
     """All repetitions of McSAS.analyse (mcsas.py:214-262) in one kernel launch."""
-    lib = _lib.load()
+    lib = _lib.load(tuning=bool(st.debug_flags))
     prob = HipProblem(model, q, intensity, sigma, st, replay, stop, smear)
     res = ChainResults(st.n_contrib, model.n_active, st.n_reps, len(prob.q))
-    check(lib.mcsas_hip_analyse(C.byref(prob.c), C.byref(res.c)))
+    check(lib.mcsas_hip_analyse(C.byref(prob.c), C.byref(res.c)), lib)
     return res
 
 
@@ -171,28 +171,28 @@ class Plan:
     """Resident plan: data and workspaces stay in HBM; launch/fetch can be repeated (bench.py)."""
 
     def __init__(self, model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, stop=None, smear=None):
-        self.lib = _lib.load()
+        self.lib = _lib.load(tuning=bool(st.debug_flags))
         self.prob = HipProblem(model, q, intensity, sigma, st, replay, stop, smear)
         self.h = C.c_void_p()
-        check(self.lib.mcsas_hip_plan_create(C.byref(self.prob.c), C.byref(self.h)))
+        check(self.lib.mcsas_hip_plan_create(C.byref(self.prob.c), C.byref(self.h)), self.lib)
 
     def launch(self, stream=None):
-        check(self.lib.mcsas_hip_plan_launch(self.h, C.c_void_p(stream or 0)))
+        check(self.lib.mcsas_hip_plan_launch(self.h, C.c_void_p(stream or 0)), self.lib)
 
     def fetch(self, want_arrays=True):
         st = self.prob.st
         res = ChainResults(st.n_contrib, self.prob.model.n_active, st.n_reps, len(self.prob.q)) if want_arrays else None
-        check(self.lib.mcsas_hip_plan_fetch(self.h, C.byref(res.c) if res is not None else None))
+        check(self.lib.mcsas_hip_plan_fetch(self.h, C.byref(res.c) if res is not None else None), self.lib)
         return res
 
     def reseed(self, seed, rep_offset=0):
-        check(self.lib.mcsas_hip_plan_reseed(self.h, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_int32(rep_offset)))
+        check(self.lib.mcsas_hip_plan_reseed(self.h, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), C.c_int32(rep_offset)), self.lib)
 
     @property
     def info(self):
         """dict: exec mode the library chose, waves per chain, q slots per lane, window, launches, cache."""
         v = (C.c_int32 * 8)()
-        check(self.lib.mcsas_hip_plan_info(self.h, v))
+        check(self.lib.mcsas_hip_plan_info(self.h, v), self.lib)
         names = {1: "wave", 2: "workgroup", 3: "pipeline"}
         return dict(exec_mode=names.get(v[0], str(v[0])), waves_per_chain=v[1], q_per_lane=v[2], window=v[3],
                     launches=v[4], cached_rows=bool(v[5]))
@@ -200,13 +200,13 @@ class Plan:
     @property
     def last_ms(self):
         v = C.c_double()
-        check(self.lib.mcsas_hip_plan_last_ms(self.h, C.byref(v)))
+        check(self.lib.mcsas_hip_plan_last_ms(self.h, C.byref(v)), self.lib)
         return v.value
 
     @property
     def total_steps(self):
         v = C.c_int64()
-        check(self.lib.mcsas_hip_plan_total_steps(self.h, C.byref(v)))
+        check(self.lib.mcsas_hip_plan_total_steps(self.h, C.byref(v)), self.lib)
         return v.value
 
     def close(self):

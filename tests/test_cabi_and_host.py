@@ -178,3 +178,26 @@ def test_shard_rule_of_the_library_is_the_one_of_dist():
             blocks = [engine.shard(n, g, i) for i in range(g)]
             assert blocks == [dist.shard_reps(n, g, i) for i in range(g)]
             assert sum(c for _, c in blocks) == n and all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(g - 1))
+
+
+def test_release_library_refuses_a_nonzero_reserved_word():
+    """mcsas_problem.reserved0 "must be 0": the tuning / ablation variants of the pipeline mode exist in the measurement
+    build only (libmcsas_hip_tuning.so, -DMCSAS_TUNING); the release library answers MCSAS_EINVAL before it touches a
+    device — a caller that fails to zero the field gets an error, not a silently different fit."""
+    import ctypes as C
+    from mcsas_amd import _lib, engine
+    import mcsas_amd
+    lib = _lib.load()
+    assert lib.mcsas_hip_is_tuning_build() == 0
+    q = np.logspace(7, 9, 64)
+    m = mcsas_amd.Sphere(); m.radius.setActiveRange((1e-9, 1e-7))
+    st = engine.Settings(n_contrib=40, n_reps=2, max_iter=10)
+    prob = engine.HipProblem(m.setup(), q, np.ones(64), np.ones(64), st)
+    prob.c.reserved0 = 1 << 16
+    h = C.c_void_p()
+    rc = lib.mcsas_hip_plan_create(C.byref(prob.c), C.byref(h))
+    assert rc == -1 and b"reserved0" in lib.mcsas_hip_last_error()
+    res = engine.ChainResults(40, 1, 2, 64)
+    assert lib.mcsas_hip_analyse(C.byref(prob.c), C.byref(res.c)) == -1
+    tl = _lib.load(tuning=True)
+    assert tl.mcsas_hip_is_tuning_build() == 1 and tl is not lib

@@ -246,8 +246,8 @@ def test_device_list_shards_repetitions_like_one_device(mode):
         for name in ("contribs", "fit", "chisq", "scaling", "background", "num_iter", "num_moves", "attempts", "converged", "draws"):
             np.testing.assert_array_equal(getattr(many, name), getattr(one, name), err_msg="%s with %d devices" % (name, len(devs)))
     # a replayed stream is split along with the repetitions
-    replay = np.stack([g["stream"][k:k + 3300] for k in (0, 50, 100, 150, 200)])
-    st3 = engine.Settings(n_contrib=200, n_reps=5, max_iter=3000, conv_crit=1e-9, max_retries=0, exec_mode=mode)
+    replay = np.stack([g["stream"][k:k + 1720] for k in (0, 50, 100, 150, 200)])
+    st3 = engine.Settings(n_contrib=200, n_reps=5, max_iter=1500, conv_crit=1e-9, max_retries=0, exec_mode=mode)
     a = engine.analyse(m.setup(), q, I, sig, st3, replay=replay)
     b = engine.analyse(m.setup(), q, I, sig, engine.Settings(**{**st3.__dict__, "devices": (0, 0)}), replay=replay)
     np.testing.assert_array_equal(a.contribs, b.contribs); np.testing.assert_array_equal(a.num_moves, b.num_moves)
