@@ -17,9 +17,12 @@ equal --gpus.  Weak scaling: every rank runs the config's per-GPU repetitions; s
 repetitions (50 / 200 / 400 / 100) are sharded over the ranks (mcsas_amd.dist.shard_reps); chain id = global
 repetition index either way, and one all-gather (RCCL) per launch assembles the results.
 
-Prints ONE JSON line (rank 0); besides the contract's keys: `roofline` (SURVEY 8d byte model against HBM peak),
-`roofline_valu` (fp64 vector-issue view of the same launches), `launch_ms` (min / median / max), `configs` (short
-fixed-budget runs of configs 3-5 at their per-GPU repetition counts) and `cpu_baseline`.
+Prints ONE JSON line (rank 0); besides the contract's keys: `roofline` (the resource the counters name for this kernel —
+fp64 vector issue — with the SURVEY 8d byte model against the HBM peak kept beside it as `algorithmic_hbm` and the
+memory-side traffic of the committed FETCH/WRITE passes as `traffic`), `launch_ms` (min / median / max), `configs`
+(configs 3-5 at their per-GPU repetition counts, each sustained over >= 1 s of back-to-back launches),
+`convergence_run` (criterion 1 as BASELINE names it), `quickstart` (the reference's published workload end to end) and
+`cpu_baseline`.
 """
 import argparse
 import json
@@ -337,38 +340,45 @@ def main():
             # actually stays on chip, so this is an algorithmic figure; `traffic` is what the memory-side
             # counters saw for the same command in the committed profile named in `traffic_source`.
             traffic, source = None, None
-            tj = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-            if args.config == 2 and info["exec_mode"] == "pipeline" and os.path.exists(tj):
-                pm = json.load(open(tj))
+            tj = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+            pm = json.load(open(tj)).get(str(args.config)) if os.path.exists(tj) else None
+            if pm and info["exec_mode"] == "pipeline" and reps == wl["reps_gpu"]:
                 traffic = (pm["fetch_bytes_per_mc_step"] + pm["write_bytes_per_mc_step"]) * steps_per_launch / launch_s / 1e9
                 source = "from_profile: %s (commit %s)" % (os.path.relpath(tj, ROOT), pm.get("commit", "?"))
-            out["roofline"] = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": source,
-                               "note": "achieved = 40*Q B per MC step (SURVEY 8d streaming model, no on-chip reuse credit) x MC steps "
-                                       "per launch / mean HIP-event time of a launch; q, I, sigma and ft stay on chip, so the figure may exceed the HBM peak"}
-            ij = os.path.join(ROOT, "profiles", "r02_valu_per_step.json")
-            if os.path.exists(ij):
-                pv = json.load(open(ij)).get(str(args.config))
-                if pv:
-                    rate = pv["valu_wave_instr_per_mc_step"] * steps_per_launch / launch_s
-                    out["roofline_valu"] = {"bound": "fp64 vector issue", "achieved": rate / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9,
-                                            "unit": "G wave-instr/s", "frac": rate / FP64_VECTOR_PEAK_INSTR,
-                                            "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
-                                            "source": "from_profile: profiles/r02_valu_per_step.json (SQ_INSTS_VALU pass, commit %s)" % pv.get("commit", "?")}
-        # outside the timed region: the same repetitions run the way McSAS.analyse runs them
-        # (maxIterations = 1e5, maxRetries = 5) -> final chi² and steps to converge.  Criterion 2: with 1 %
-        # noise on the synthetic curve 400 spheres plateau at chi² ~1.15 after 1e5 steps, so the default
-        # criterion 1 is never met on this data set (every repetition then burns all 6 attempts)
-        CRIT = 2.0
+            algorithmic = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                           "note": "40*Q B per MC step (SURVEY 8d streaming model, no on-chip reuse credit) x MC steps per launch / mean "
+                                   "HIP-event time of a launch; q, I, sigma and ft stay on chip, so this is not memory traffic"}
+            ij = os.path.join(ROOT, "profiles", "r03_valu_per_step.json")
+            pv = json.load(open(ij)).get(str(args.config)) if os.path.exists(ij) else None
+            if pv and info["exec_mode"] == "pipeline":
+                rate = pv["valu_wave_instr_per_mc_step"] * steps_per_launch / launch_s
+                out["roofline"] = {"bound": "valu", "achieved": rate / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9,
+                                   "unit": "G wave-instr/s", "frac": rate / FP64_VECTOR_PEAK_INSTR, "traffic": traffic,
+                                   "traffic_unit": "GB/s", "traffic_source": source,
+                                   "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
+                                   "source": "from_profile: profiles/r03_valu_per_step.json (SQ_INSTS_VALU pass, commit %s)" % pv.get("commit", "?"),
+                                   "note": "fp64 vector issue: 1024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz; achieved = "
+                                           "SQ_INSTS_VALU per MC step (committed counter pass) x MC steps per launch / mean HIP-event time of a launch",
+                                   "algorithmic_hbm": algorithmic}
+            else:
+                out["roofline"] = dict(algorithmic, traffic=traffic, traffic_source=source)
+        # outside the timed region: the same repetitions run the way McSAS.analyse runs them — convergenceCriterion 1 (BASELINE),
+        # maxIterations 1e5, one attempt — -> final chi² and how many got there.  (With 1 % noise on the synthetic curve 400
+        # spheres plateau near chi² 1.15: the criterion is out of reach on THIS data set and every chain runs its full budget;
+        # the reference's own published workload, where criterion 1 is reached, is the `quickstart` entry.)
         if not dry and not args.no_convergence_run and args.config == 2:
-            stc = engine.Settings(n_contrib=ncontrib, n_reps=reps, max_iter=100000, conv_crit=CRIT, max_retries=5,
+            stc = engine.Settings(n_contrib=ncontrib, n_reps=reps, max_iter=100000, conv_crit=1.0, max_retries=0,
                                   seed=20250101, rep_offset=first, device=dev_index, exec_mode=args.mode)
             t0 = time.perf_counter()
             conv = engine.analyse(setup, q, I, sigma, stc)
-            out["convergence_run"] = {"criterion": CRIT, "wall_s": time.perf_counter() - t0,
+            wall = time.perf_counter() - t0
+            out["convergence_run"] = {"criterion": 1.0, "max_iterations": 100000, "wall_s": wall,
                                       "converged": int(conv.converged.sum()), "reps": reps,
-                                      "chisq_max": float(conv.chisq.max()), "chisq_mean": float(conv.chisq.mean()),
-                                      "steps_mean": float(conv.num_iter.mean()), "attempts_max": int(conv.attempts.max())}
+                                      "chisq_min": float(conv.chisq.min()), "chisq_median": float(np.median(conv.chisq)),
+                                      "chisq_max": float(conv.chisq.max()), "steps_mean": float(conv.num_iter.mean()),
+                                      "mc_steps_per_s_incl_setup": float(conv.num_iter.sum()) / wall}
+        if not dry and not args.no_convergence_run and world == 1 and args.config == 2:
+            out["quickstart"] = quickstart(dev_index)
         if not dry and not args.no_configs and world == 1 and args.config == 2:
             out["configs"] = other_configs(dev_index)
         if not dry and not args.no_cpu_baseline and world == 1 and args.config == 2:   # the CPU baseline is timed at N = 1 only
@@ -379,46 +389,103 @@ def main():
         tdist.destroy_process_group()
 
 
-def other_configs(dev_index):
-    """Short fixed-budget runs of BASELINE configs 3-5 at their per-GPU repetition counts (200 / 400 / 100 repetitions
-    over 8 GPUs -> 25 / 50 / 13).  The chain initialisation (N form-factor rows per chain) is timed by a zero-step
-    launch of the same plan shape and reported beside the MC-step rate."""
+def other_configs(dev_index, seconds=1.0):
+    """BASELINE configs 3-5 at their per-GPU repetition counts (200 / 400 / 100 repetitions over 8 GPUs -> 25 / 50 / 13),
+    SUSTAINED: back-to-back launches of a fixed budget until at least `seconds` of wall time have passed (device
+    synchronised on both sides), value = all MC steps / that time — chain initialisation (N form-factor rows per chain and
+    launch) included.  The initialisation alone (a zero-step launch of the same plan, median of three) is reported beside
+    it, and the rate with it taken out as a secondary figure."""
+    import torch
     from mcsas_amd import engine
     out = {}
-    ij = os.path.join(ROOT, "profiles", "r02_valu_per_step.json")
+    ij = os.path.join(ROOT, "profiles", "r03_valu_per_step.json")
     prof = json.load(open(ij)) if os.path.exists(ij) else {}
-    for cfg, budget in ((3, 2000), (4, 1000), (5, 1000)):
+    tj = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    traf = json.load(open(tj)) if os.path.exists(tj) else {}
+    for cfg, budget in ((3, 10000), (4, 5000), (5, 5000)):
         wl = workload(cfg)
         setup = wl["model"].setup()
-        times = {}
-        for label, steps in (("init", 0), ("run", budget)):
-            st = engine.Settings(n_contrib=wl["n"], n_reps=wl["reps_gpu"], max_iter=steps, conv_crit=0.0, max_retries=0,
-                                 seed=20250101, device=dev_index)
-            plan = engine.Plan(setup, wl["q"], wl["I"], wl["sigma"], st)
-            ms = []
-            for rep in range(3):
-                plan.reseed(77 + rep, 0); plan.launch(); res = plan.fetch(); ms.append(plan.last_ms)
-            times[label] = (min(ms), plan.total_steps, plan.info, float(np.median(res.chisq)))
-            plan.close()
-        t_init, t_run = times["init"][0], times["run"][0]
-        steps = times["run"][1]
-        rate = steps / max((t_run - t_init) * 1e-3, 1e-9)
-        pts = 2 * len(wl["q"]) * wl["K"]           # SURVEY 8d: T_step = 2 Q K form-factor points (new + old)
-        e = {"workload": "%s, %d reps (per-GPU share of %d), %d MC steps per chain" % (wl["name"], wl["reps_gpu"], wl["reps_total"], budget),
-             "value": rate, "unit": "MC steps/s", "init_ms": t_init, "run_ms": t_run, "exec_mode": times["run"][2]["exec_mode"],
-             "window": times["run"][2]["window"], "final_chisq_median": times["run"][3],
-             "ff_points_per_s_survey_model": rate * pts,
-             "roofline": {"bound": "hbm", "achieved": 40 * len(wl["q"]) * rate / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                          "frac": 40 * len(wl["q"]) * rate / HBM_PEAK, "traffic": None}}
+        st0 = engine.Settings(n_contrib=wl["n"], n_reps=wl["reps_gpu"], max_iter=0, conv_crit=0.0, max_retries=0,
+                              seed=20250101, device=dev_index)
+        plan0 = engine.Plan(setup, wl["q"], wl["I"], wl["sigma"], st0)
+        init_ms = []
+        for rep in range(4):
+            plan0.reseed(70 + rep, 0); plan0.launch(); plan0.fetch(want_arrays=False); init_ms.append(plan0.last_ms)
+        plan0.close()
+        init = float(np.median(init_ms[1:]))
+        st = engine.Settings(n_contrib=wl["n"], n_reps=wl["reps_gpu"], max_iter=budget, conv_crit=0.0, max_retries=0,
+                             seed=20250101, device=dev_index)
+        plan = engine.Plan(setup, wl["q"], wl["I"], wl["sigma"], st)
+        plan.reseed(76, 0); plan.launch(); plan.fetch(want_arrays=False)          # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps, ms, n, res = 0, [], 0, None
+        while True:
+            plan.reseed(77 + n, 0); plan.launch(); res = plan.fetch()
+            steps += plan.total_steps; ms.append(plan.last_ms); n += 1
+            if time.perf_counter() - t0 >= seconds:
+                break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        info = plan.info
+        plan.close()
+        rate = steps / dt
+        dev_s = float(np.sum(ms)) * 1e-3
+        nq = len(wl["q"])
+        pts = nq * wl["K"]                                    # form-factor points evaluated per MC step: the `new` row (`old` comes from the row cache)
+        e = {"workload": "%s, %d reps (per-GPU share of %d), %d MC steps per chain per launch" % (wl["name"], wl["reps_gpu"], wl["reps_total"], budget),
+             "value": rate, "unit": "MC steps/s", "timed_region_s": dt, "launches": n, "mc_steps": steps,
+             "launch_ms": {"min": float(np.min(ms)), "median": float(np.median(ms)), "max": float(np.max(ms))},
+             "init_ms": init, "value_excl_init": steps / max(dev_s - n * init * 1e-3, 1e-9),
+             "exec_mode": info["exec_mode"], "window": info["window"], "final_chisq_median": float(np.median(res.chisq)),
+             "ff_points_per_s": rate * pts, "ff_points_per_mc_step": pts}
+        alg = {"bound": "hbm", "achieved": 40 * nq * rate / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 40 * nq * rate / HBM_PEAK}
         pv = prof.get(str(cfg))
+        tr = traf.get(str(cfg))
+        traffic = (tr["fetch_bytes_per_mc_step"] + tr["write_bytes_per_mc_step"]) * rate / 1e9 if tr else None
         if pv:
             r = pv["valu_wave_instr_per_mc_step"] * rate
-            e["roofline_valu"] = {"bound": "fp64 vector issue", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9,
-                                  "unit": "G wave-instr/s", "frac": r / FP64_VECTOR_PEAK_INSTR,
-                                  "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
-                                  "source": "from_profile: profiles/r02_valu_per_step.json (commit %s)" % pv.get("commit", "?")}
+            e["roofline"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
+                             "frac": r / FP64_VECTOR_PEAK_INSTR, "traffic": traffic, "traffic_unit": "GB/s",
+                             "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
+                             "source": "from_profile: profiles/r03_valu_per_step.json / r03_pmc_traffic.json (commit %s)" % pv.get("commit", "?"),
+                             "algorithmic_hbm": alg}
+        else:
+            e["roofline"] = dict(alg, traffic=traffic)
         out[str(cfg)] = e
     return out
+
+
+def quickstart(dev_index):
+    """The one workload the reference publishes a time for (doc/source/quickstart.rst:66-107: Sphere on
+    testdata/quickstartdemo1.csv, 10 repetitions x 300 contributions, convergence criterion 1, one 50-bin log histogram:
+    "36 seconds on a 3.4 GHz intel i7 iMac"): McSAS.calc() — analyse() AND histogram() — on the data vectors of the fixture
+    the reference itself was run on in the build container (tests/golden/g13_quickstart.npz; its calc() took 23.6 s there)."""
+    import mcsas_amd
+    path = os.path.join(ROOT, "tests", "golden", "g13_quickstart.npz")
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    lo, hi = float(g["lo"]), float(g["hi"])
+    walls, chis, iters = [], None, None
+    for trial in range(4):                                     # the first call pays library / device start-up
+        m = mcsas_amd.Sphere(); m.radius.setActiveRange((lo, hi))
+        m.radius.histograms().append(mcsas_amd.Histogram(m.radius, lo, hi, binCount=50, xscale='log', yweight='vol'))
+        algo = mcsas_amd.McSAS(seed=100 + trial, device=dev_index)
+        algo.numContribs.setValue(300); algo.numReps.setValue(10); algo.convergenceCriterion.setValue(1.0)
+        algo.model = m
+        algo.data = mcsas_amd.SASData(g["data_q"], g["data_I"], g["data_sigma"], f_limit=g["data_f_limit"])
+        t0 = time.perf_counter()
+        algo.calc()
+        walls.append(time.perf_counter() - t0)
+        chis, iters = algo.details.chisq, algo.details.num_iter
+    return {"workload": "Sphere, testdata/quickstartdemo1.csv (100 q after the reference's rebinning), 10 reps x 300 contribs, "
+                        "convergenceCriterion 1, McSAS.calc() incl. histogram()",
+            "quickstart_wall_s": float(np.median(walls[1:])), "first_call_wall_s": float(walls[0]),
+            "chisq_max": float(np.max(chis)), "converged": int((chis <= 1.0).sum()), "steps_mean": float(np.mean(iters)),
+            "reference_doc_wall_s": 36.0, "reference_doc_source": "doc/source/quickstart.rst:106-107 (3.4 GHz i7 iMac, 2012)",
+            "reference_here_wall_s": float(g["wall_s"]),
+            "reference_here_source": "oracle/make_golden.py gen_quickstart: the reference's calc() in the build container (1 core)"}
 
 
 if __name__ == "__main__":

@@ -117,10 +117,15 @@ struct PipeArgs {
 // through the argument block in device memory costs a dependent global round trip before the first useful load can be
 // issued — pointer, then data — on the critical path of every tick.
 struct PipeHot {
-    const double *q, *w, *wI;
+    const double *q, *w, *wI, *q3inv;                          // q3inv = 1 / q^3, host-made (the same IEEE operations as on the device)
     PipeChain *chains;
-    int32_t n_reps, n_contrib, n_active, qpad, kb, prod_blocks_y, w_sub, pad;
+    int32_t n_reps, n_contrib, n_active, qpad, kb, prod_blocks_y, w_sub, sub_per_block;
     int64_t max_iter;
+    // rows without an integral, lazy row cache: what a producer block asks memory for before it has seen its chain's
+    // schedule record (speculating on attempt 0)
+    double *rset, *cache;
+    int32_t *row_valid;
+    int32_t cache_rows, light_lazy, skew, light;               // light: rows without an integral on the LDS / overlapped producer
 };
 
 // schedule records go through scalar global loads / stores (a struct copy out of an address-space-qualified
@@ -178,18 +183,27 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         if (2 * 8 * rpw > n_contrib) return 1;
         by = n_contrib / (2 * 8 * rpw);
         if (by * 8 * rpw > 256) by = 256 / (8 * rpw);
-        // Rows with an integral: a block's time is one row per wave whatever the window, and the launch takes
-        // ceil(blocks / CUs) such rounds — the producer blocks per chain that give the most steps per round win
-        // (13 Kholodenko chains: 18 blocks per chain = 247 blocks in ONE round and 144 steps, instead of 32 = 429
-        // blocks in two rounds for 256)
+        // Rows with an integral: a block's time is its waves' rows whatever the window, and the launch takes
+        // ceil(blocks / CUs) such rounds — the rows per wave and the producer blocks per chain that give the most steps per
+        // unit of time win (13 Kholodenko chains: 18 blocks per chain = 247 blocks in ONE round, instead of 32 = 429 blocks
+        // in two).  heavy_rows == 2: the cost of a row varies with its parameters (worm-like chains: up to 5x with the Kuhn
+        // length; cylinders: with the Bessel function's branch).  With one row per wave a round lasts as long as the chip's
+        // most expensive row (factor ~1.5 over the mean); two rows per wave, dealt by predicted cost (pipe_prod_block), bring a
+        // wave's total within ~10 % of the mean and double the window a round covers.
         if (heavy_rows && rows_per_wave_req == 0 && n_chains > 0 && n_cus > 0) {
-            int best = by; double best_rate = 0.;
-            for (int b = 1; b <= by; ++b) {
-                const int rounds = (n_chains * (b + 1) + n_cus - 1) / n_cus;
-                const double rate = (double)(b * 8 * rpw) / rounds;
-                if (rate >= best_rate) { best_rate = rate; best = b; }
+            static const double spread[5] = {0., 1.5, 1.12, 1.08, 1.06};       // a round's duration / (rows per wave x mean row), varying costs
+            int best_r = 1, best_b = by; double best_rate = 0.;
+            for (int r = 1; r <= (heavy_rows == 2 ? 4 : 1); ++r) {
+                if (2 * 8 * r > n_contrib) break;
+                int bmax = n_contrib / (2 * 8 * r);
+                if (bmax * 8 * r > 256) bmax = 256 / (8 * r);
+                for (int b = 1; b <= bmax; ++b) {
+                    const int rounds = (n_chains * (b + 1) + n_cus - 1) / n_cus;
+                    const double rate = (double)(b * 8 * r) / (rounds * r * (heavy_rows == 2 ? spread[r] : 1.0));
+                    if (rate > best_rate * (1.0 + 1e-9) || (rate >= best_rate * (1.0 - 1e-9) && r == best_r && b > best_b)) { best_rate = rate; best_r = r; best_b = b; }
+                }
             }
-            by = best;
+            rpw = best_r; by = best_b;
         }
     } else {
         static const int order[6] = {6, 8, 4, 3, 2, 1};
@@ -728,20 +742,109 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     const int64_t max_iter = hot.max_iter;                    // (a field of the argument block read inside the row loop would be a global load + full wait per row)
     // the data tables do not depend on the chain's schedule record: both round trips run side by side
     constexpr int QTB = (QPL * 64 + PIPE_BLOCK - 1) / PIPE_BLOCK;
-    double tq[QTB], tw[QTB], twI[QTB];
+    double tq[QTB], tw[QTB], twI[QTB], tq3[QTB];
 #pragma unroll
     for (int x = 0; x < QTB; ++x) {
         const int i = tid + PIPE_BLOCK * x < qpad ? tid + PIPE_BLOCK * x : 0;
-        tq[x] = glb(hot.q)[i]; tw[x] = glb(hot.w)[i]; twI[x] = glb(hot.wI)[i];
+        tq[x] = glb(hot.q)[i]; tw[x] = glb(hot.w)[i]; twI[x] = glb(hot.wI)[i]; tq3[x] = glb(hot.q3inv)[i];
+    }
+    // ---- rows without an integral, lazy row cache: the `old` side of my rows — validity flags, parameter sets and the first
+    // `old` row — is requested NOW, beside the tables and the schedule record, on the guess that the chain is in its first
+    // attempt (t_init = 0); a chain that has been restarted asks again once the record is here (one more round trip)
+    struct RowShare { int W, nsb, BR, RW, rbase, nmine; };
+    RowShare rs_{};
+    int sp_valid = 1, sp_r = -1;                              // speculative: flag and contribution of lane 32 + l's row l
+    double sp_prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+    double sp_ocur[QPL];
+#pragma unroll
+    for (int j = 0; j < QPL; ++j) sp_ocur[j] = 0.;
+    int64_t sb0_guess = -1;
+    const int wv0 = __builtin_amdgcn_readfirstlane(wave);
+    auto old_side = [&](int64_t sb0, int &v, int &r_out, double (&pr)[MCSAS_MAX_ACTIVE], double (&oc)[QPL]) {
+        const int l2 = lane - 32;
+        v = 1; r_out = -1;
+        if (l2 >= 0 && l2 < rs_.nmine) {
+            const int lrow_o = (l2 / rs_.RW) * rs_.W + rs_.rbase + (l2 % rs_.RW);
+            if (sb0 + lrow_o < max_iter) {
+                const int r = (int)((sb0 + lrow_o) % N);
+                r_out = r;
+                v = glb(hot.row_valid)[(size_t)rep * N + r];
+#pragma unroll
+                for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) if (p < P) pr[p] = glb(hot.rset)[((size_t)rep * N + r) * P + p];
+            }
+        }
+        const int r0 = (int)((sb0 + rs_.rbase) % N);          // my first row's contribution (its row slot: lazy rows never move)
+        const auto orow0 = glb(hot.cache) + ((size_t)rep * hot.cache_rows + r0) * qpad + lane;
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) oc[j] = orow0[WAVE * j];
+    };
+    // Rows per wave and sub-window: W / 8 on average, the four waves that share their SIMDs with an older wave (4-7) give
+    // `skew` rows to the older ones (0-3) (host: 1 for the LDS variant — the SIMD arbitrates oldest-first, so with equal
+    // shares the older wave is done early and the younger one finishes the phase alone, latency-bound: measured 4 + 2 rows
+    // 3.92 ms, 3 + 3 4.03, 5 + 1 4.2)
+    if constexpr (pipe_light_model(M)) if (hot.light) {
+        const int W = hot.w_sub, rw_even = W >> 3, skew = hot.skew < rw_even ? hot.skew : rw_even - 1;
+        rs_.W = W; rs_.nsb = hot.sub_per_block; rs_.BR = rs_.nsb * W;
+        rs_.RW = wv0 < 4 ? rw_even + skew : rw_even - skew;                           // my rows per sub-window
+        rs_.rbase = wv0 < 4 ? wv0 * (rw_even + skew) : 4 * (rw_even + skew) + (wv0 - 4) * (rw_even - skew);   // my first row in a sub-window
+        rs_.nmine = rs_.nsb * rs_.RW;
+        if (hot.light_lazy && t >= 1) {
+            sb0_guess = ((int64_t)t - 1) * Kb + (int64_t)by * rs_.BR;
+            old_side(sb0_guess, sp_valid, sp_r, sp_prow, sp_ocur);
+        }
     }
     const PipeSnap sn = load_snap(&hot.chains[rep].snap[t & 1]);
     if (!sn.alive || t < sn.t_init) return;
+
+    // ---- rows without an integral, a window tick: the proposals of my rows (lane l <-> my l-th row; random stream, generator
+    // transform) and ONE prepare() for them and for the `old` parameter sets of the mirror lanes 32 + l — worked out HERE, while
+    // the tables are still on their way: nothing in it needs them
+    struct LightPre { double prow[MCSAS_MAX_ACTIVE]; Contrib<M> prop; int pov, my_oslot, my_sslot, stale_r; bool old_lane; };
+    LightPre lp_{};
+    const bool light_win = pipe_light_model(M) && hot.light && t > sn.t_init && !(MCSAS_TUNE_BITS(a) & 16);
+    if constexpr (pipe_light_model(M)) if (light_win) {
+        const int W = rs_.W, BR = rs_.BR, RW = rs_.RW, rbase = rs_.rbase, nmine = rs_.nmine, buf = t & 1;
+        const bool lazy = hot.light_lazy;
+        const int64_t sb0 = ((int64_t)t - sn.t_init - 1) * Kb + (int64_t)by * BR;      // global step of the block's first row
+        const int lrow = (lane / RW) * W + rbase + (lane % RW);                        // my lane's row: its offset in the block
+        const int l2 = lane - 32;
+        lp_.old_lane = lazy && l2 >= 0 && l2 < nmine;
+        if (lazy && sb0 != sb0_guess) old_side(sb0, sp_valid, sp_r, sp_prow, sp_ocur);   // (a restarted chain, or tick 0)
+        lp_.stale_r = -1; lp_.pov = 0; lp_.my_oslot = 0; lp_.my_sslot = 0;
+#pragma unroll
+        for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) lp_.prow[p] = 0.;
+        if (lp_.old_lane && sp_r >= 0) {
+#pragma unroll
+            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) lp_.prow[p] = sp_prow[p];
+            if (!sp_valid) lp_.stale_r = sp_r;
+        }
+        const DrawSource src{a.replay ? a.replay + (size_t)rep * a.replay_len : nullptr, a.replay_len, a.seed,
+                             (uint32_t)(a.rep_offset + rep)};
+        const int r = (int)((sb0 + lrow) % N);
+        if (lane < nmine) {
+            if (lazy) lp_.my_oslot = r;
+            else {
+                lp_.my_oslot = glb(pa.slot_of)[(size_t)rep * N + r];
+                lp_.my_sslot = glb(pa.stage_slot)[(size_t)rep * 2 * Kb + buf * Kb + by * BR + lrow];
+            }
+        }
+        const int64_t sl = sb0 + lrow;
+#pragma unroll
+        for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+            if (p < P) {
+                double u = 0.5;
+                if (lane < nmine && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, lp_.pov);
+                const double pv = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
+                if (!(lp_.old_lane && sp_r >= 0)) lp_.prow[p] = pv;
+            }
+        lp_.prop.prepare(a.model, lp_.prow);
+    }
 
     double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
 #pragma unroll
     for (int x = 0; x < QTB; ++x) {
         const int i = tid + PIPE_BLOCK * x;
-        if (i < qpad) { lq[i] = tq[x]; lw[i] = tw[x]; lwI[i] = twI[x]; lq3[i] = 1.0 / (tq[x] * tq[x] * tq[x]); }
+        if (i < qpad) { lq[i] = tq[x]; lw[i] = tw[x]; lwI[i] = twI[x]; lq3[i] = tq3[x]; }
     }
     Contrib<M>::fill_table(a.model, tab, tid, PIPE_BLOCK);
     if (tid == 0) *reinterpret_cast<int32_t *>(lds + pa.g.gram_off + 16) = 0;   // lazy rows: the block's stale-row count
@@ -797,28 +900,13 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     }
 
     if (MCSAS_TUNE_BITS(a) & 16) return;                                  // diagnostic: no window rows
-    if constexpr (pipe_light_model(M)) if (pa.g.overlap || pa.g.gram_lds) {   // (rows with an integral never take this path: not instantiated for them)
-        // ---- overlapped producer.  The block's rows are nsb sub-windows of W; phase ss = the rows of sub-window ss, every
-        // wave its share, d = new - old straight to the window buffer.  The Gram block of sub-window ss - 1 is worked off
-        // in units BETWEEN the rows of phase ss (matrix pipe beside the vector pipe: while one wave of a SIMD is inside a run
-        // of MFMAs its partner has the vector issue slots to itself), its operands read back from the window buffer.
-        // One barrier per phase, and it waits for no memory: a wave passes B(ss - 1) — "the rows of ss - 1 are visible to the
-        // workgroup" — behind its FIRST row of phase ss, after a counted wait that covers exactly its stores of phase
-        // ss - 1 (the counter is in order: everything older than that row's own stores has completed by then).  The partial
-        // tiles of a block are parked in LDS when a wave has done its last unit and summed by all threads behind the next
-        // barrier (two reduction buffers, by parity).  Only the last sub-window's Gram block runs with nothing beside it.
-        const int W = pa.g.w, nsb = pa.g.sub_per_block, BR = nsb * W;
-        // Rows per wave and sub-window: W / 8 on average; tuning bits 19-20 shift rows from the four waves that share
-        // their SIMDs with an older wave (4-7) to the older ones (0-3): 0 = equal shares, 1 / 2 = one / two rows.
-        // (the LDS variant's default is one row: the SIMD arbitrates oldest-first, so with equal shares the older wave is done
-        // early and the younger one finishes the phase alone, latency-bound — measured 4 + 2 rows 3.92 ms, 3 + 3 4.03, 5 + 1 4.2;
-        // bits 19-20 = 3 there: equal shares)
-        const int rw_even = W >> 3, skew_bits = (MCSAS_TUNE_BITS(a) >> 19) & 3;
-        const int skew_req = pa.g.gram_lds ? (skew_bits == 0 ? 1 : (skew_bits == 3 ? 0 : skew_bits)) : skew_bits;
-        const int skew = skew_req < rw_even ? skew_req : rw_even - 1;
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const int RW = wv < 4 ? rw_even + skew : rw_even - skew;                        // my rows per sub-window
-        const int rbase = wv < 4 ? wv * (rw_even + skew) : 4 * (rw_even + skew) + (wv - 4) * (rw_even - skew);   // my first row in a sub-window
+    if constexpr (pipe_light_model(M)) if (hot.light) {           // (rows with an integral never take this path: not instantiated for them)
+        // ---- rows without an integral.  The block's rows are nsb sub-windows of W steps, every wave its share of each
+        // (rs_); d = new - old goes to the window buffer, the sub-window's Gram block is taken with fp64 MFMAs.  Default (LDS
+        // variant): rows of a sub-window, barrier, Gram block from the LDS copy of its d rows, next sub-window.  Measurement
+        // builds also carry the overlapped variant (Gram units of sub-window s between the rows of s + 1, operands read back
+        // from the window buffer in HBM/L2): see rows_and_gram below.
+        const int W = rs_.W, nsb = rs_.nsb, BR = rs_.BR, RW = rs_.RW, rbase = rs_.rbase, nmine = rs_.nmine, wv = wv0;
         const int buf = t & 1;
         const int64_t w = (int64_t)t - sn.t_init - 1;
         const int64_t sb0 = w * Kb + (int64_t)by * BR;                                 // global step of the block's first row
@@ -827,68 +915,45 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
         auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
         auto gwin = glb(pa.gwin) + ((size_t)rep * 2 + buf) * Kb * W;
-        double *gred = lds + pa.g.gram_off + 16;                                       // [2][8 waves][PIPE_GRAM_NT_MAX][256]
+        double *gred = lds + pa.g.gram_off + 16;                                       // Gram reduction buffer (the stale-row hand-over uses it first)
         constexpr size_t GRED = (size_t)PIPE_WAVES * PIPE_GRAM_NT_MAX * 256;
-        const int nmine = nsb * RW;                                                    // my rows (<= 8), lane l <-> my l-th row
         const bool no_gram = MCSAS_TUNE_BITS(a) & 64;                                              // diagnostic: no Gram blocks (uniform)
         const int lrow = (lane / RW) * W + rbase + (lane % RW);                        // its offset in the block
-        const bool lazy = pa.g.lazy_rows;
+        const bool lazy = hot.light_lazy;
         PIPE_TLX_MARK(pa, t, 0);
         // ---- lazy rows: the block's stale `old` rows (their last proposal, N steps ago, was accepted: ~6 % of them) are
         // evaluated again from the parameter set, one q per thread and row — an eighth of a wave's row time for the whole
         // block, and no wave ends up with more rows than the others — and written back to the row cache.  Lanes 32 + l of
-        // a wave mirror its lanes l: the same rows, their `old` side — validity flag and parameter set in one round trip
-        // (under way while the proposals are drawn), and ONE prepare() call serves the proposals and the old sets.
+        // a wave mirror its lanes l: the same rows, their `old` side — validity flag and parameter set (requested at the
+        // block's entry); the proposals and the Contrib records of both were prepared before the tables' barrier (lp_).
         constexpr int CON = 12;                                   // doubles per Contrib record in LDS
         static_assert(sizeof(Contrib<M>) <= 8 * CON && sizeof(Contrib<M>) % 8 == 0, "Contrib record");
         int32_t *stl = reinterpret_cast<int32_t *>(gred);         // [0] count (zeroed before the tables' barrier), then the stale contributions
-        double *scon = gred + 64;                                 // their Contrib records
-        double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
-        const int l2 = lane - 32;
-        const bool old_lane = lazy && l2 >= 0 && l2 < nmine;
-        int stale_r = -1;
-        if (old_lane) {
-            const int lrow_o = (l2 / RW) * W + rbase + (l2 % RW);
-            if (sb0 + lrow_o < max_iter) {
-                const int r = (int)((sb0 + lrow_o) % N);
-                const int v = row_valid[r];
-#pragma unroll
-                for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) if (p < P) prow[p] = rset[(size_t)r * P + p];
-                if (!v) stale_r = r;
-            }
-        }
-        int pov = 0, my_oslot = 0, my_sslot = 0;
-        {
-            const int r = (int)((sb0 + lrow) % N);
-            if (lane < nmine) {
-                if (lazy) my_oslot = r;
-                else { my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + by * BR + lrow]; }
-            }
-            const int64_t sl = sb0 + lrow;
-#pragma unroll
-            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
-                if (p < P) {
-                    double u = 0.5;
-                    if (lane < nmine && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
-                    const double pv = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
-                    if (!(old_lane && sb0 + ((l2 / RW) * W + rbase + (l2 % RW)) < max_iter)) prow[p] = pv;
-                }
-        }
-        Contrib<M> prop;
-        prop.prepare(a.model, prow);
+        double *scon = gred + 64;                                 // their Contrib records (up to 64)
+        double *stash = gred + 1024;                              // the refreshed rows themselves, for the rows of the first sub-window
+        const int stash_cap = (PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256 - 1024) / qpad;   // (the smallest reduction buffer: 32 KB)
+        double (&prow)[MCSAS_MAX_ACTIVE] = lp_.prow;
+        const Contrib<M> &prop = lp_.prop;
+        const int pov = lp_.pov, my_oslot = lp_.my_oslot, my_sslot = lp_.my_sslot, stale_r = lp_.stale_r;
         PIPE_TLX_MARK(pa, t, 1);
-        int nst = 0;
+        // my_stash (lanes 32 + l): >= 0 = row l's `old` row is stale and its fresh copy sits in stash row my_stash
+        int my_stash = -1;
+        bool stash_ok = true;
         if (lazy) {
             if (stale_r >= 0) {
                 const int e = atomicAdd(&stl[0], 1);
-                stl[1 + e] = stale_r;
-                double tmp[CON] = {};
-                __builtin_memcpy(tmp, &prop, sizeof(Contrib<M>));
+                if (e < 64) {
+                    stl[1 + e] = stale_r;
+                    double tmp[CON] = {};
+                    __builtin_memcpy(tmp, &prop, sizeof(Contrib<M>));
 #pragma unroll
-                for (int i = 0; i < (int)(sizeof(Contrib<M>) / 8); ++i) scon[e * CON + i] = tmp[i];
+                    for (int i = 0; i < (int)(sizeof(Contrib<M>) / 8); ++i) scon[e * CON + i] = tmp[i];
+                }
+                my_stash = e;
             }
             PIPE_LDS_BARRIER();
-            nst = stl[0];
+            const int nst = stl[0];                               // (<= 64: a block has at most 64 rows)
+            stash_ok = pa.g.gram_lds && nst <= stash_cap;         // uniform in the block (the overlapped variant of a measurement build: never)
             for (int i = 0; i < nst; ++i) {                       // (list order varies from run to run, the rows do not depend on it)
                 const int r = stl[1 + i];
                 Contrib<M> c;
@@ -901,12 +966,19 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
 #pragma unroll
                 for (int x = 0; x < QTB; ++x) {
                     const int iq = tid + PIPE_BLOCK * x;
-                    if (iq < qpad) cache[(size_t)r * qpad + iq] = pipe_point_intensity<M>(c, lq[iq], lq3[iq], tab);
+                    if (iq < qpad) {
+                        const double v = pipe_point_intensity<M>(c, lq[iq], lq3[iq], tab);
+                        cache[(size_t)r * qpad + iq] = v;
+                        if (stash_ok) stash[(size_t)i * qpad + iq] = v;
+                    }
                 }
                 if (tid == 0) row_valid[r] = 1;
             }
-            if (nst) __syncthreads();                             // the refreshed rows have landed before the row loop loads them (uniform)
-            else PIPE_LDS_BARRIER();                              // (the stale list shares the reduction buffer: read by all before it is reused)
+            // The fresh rows reach the waves that need them as `old` through LDS (first sub-window) — no wait for the stores, no
+            // second trip to memory — or, past the first sub-window's barrier, from the row cache (every storing wave has waited
+            // for its loads, hence for these older stores, in its first row).  More stale rows than the hand-over buffer holds
+            // (never seen at ~6 % acceptance): the stores are waited for and everything comes from the row cache.
+            if (nst) { if (stash_ok) PIPE_LDS_BARRIER(); else __syncthreads(); }
         }
         PIPE_TLX_MARK(pa, t, 2);
         PIPE_TLX_MARK(pa, t, 3);
@@ -928,7 +1000,10 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
             const int dstr = qpad + PIPE_DROW_PAD;
             double *dbuf = lds + pa.g.drow_off;
             double ocur[QPL], onext[QPL];
-            {
+            if (lazy) {
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) ocur[j] = sp_ocur[j];                   // requested at the block's entry
+            } else {
                 const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
@@ -954,6 +1029,22 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                     double *dl = dbuf + (size_t)(rbase + jr) * dstr + lane;
                     RowEval<M, QPL>::run(cnew, qt, lane, nwv);
                     PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
+                    // a stale `old` row was evaluated again at the block's start: what memory returned for it may predate that
+                    const int e_l = __builtin_amdgcn_readlane(my_stash, 32 + bl);
+                    if (e_l >= 0) {                                                 // uniform in the wave, ~6 % of the rows
+                        if (ss == 0 && stash_ok) {
+                            const double *srow = stash + (size_t)e_l * qpad + lane;
+#pragma unroll
+                            for (int j = 0; j < QPL; ++j) ocur[j] = srow[WAVE * j];
+                        } else if (jr == 0) {
+                            // requested before the barrier behind which the fresh row is visible in the row cache (a later
+                            // sub-window's first row; or the block's first row when the hand-over buffer was too small)
+                            const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bl) * qpad + lane;
+#pragma unroll
+                            for (int j = 0; j < QPL; ++j) ocur[j] = orow[WAVE * j];
+                            PIPE_PIN_ROW(ocur);
+                        }
+                    }
                     double s1 = 0., s2 = 0.;
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {
@@ -1106,11 +1197,16 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     MCSAS_STAMP_DECL(pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0);
     MCSAS_STAMP(pp0);
     PIPE_TLX_MARK(pa, t, 0);
-    // ---- window w of the attempt: this wave's rows k = gw*rpw .. +rpw-1, one proposal per lane
+    // ---- window w of the attempt, rows with an integral (or a smeared model).  The block owns BR = 8 rpw consecutive steps
+    // and EVERY wave works out the proposals of all of them (lane l <-> block row l: the lanes are there anyway).  With more
+    // than one row per wave the rows are dealt by predicted cost (models.h: row_cost) — wave v takes the v-th most expensive,
+    // the (16 - 1 - v)-th, the (16 + v)-th ... (boustrophedon over the cost ranking) — so that every wave carries about the
+    // same total: a worm's row costs up to five times another's (its Kuhn length sets the number of quadrature panels), and
+    // with one row per wave the tick lasts as long as the chip's most expensive row while most waves sit idle.
     const int64_t w = (int64_t)t - sn.t_init - 1;
-    const int rpw = pa.g.rows_per_wave, buf = t & 1;
-    const int k0 = gw * rpw;
-    const int64_t s0 = w * Kb + k0;
+    const int rpw = pa.g.rows_per_wave, buf = t & 1, BR = 8 * rpw;
+    const int kb0 = by * BR;                                      // the block's first row in the window
+    const int64_t s0 = w * Kb + kb0;
     double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
     int pov = 0;
     {
@@ -1119,30 +1215,46 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
             if (p < P) {
                 double u = 0.5;
-                if (lane < rpw && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
+                if (lane < BR && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
                 prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
             }
     }
     Contrib<M> prop;
     prop.prepare(a.model, prow);
+    // rank of my lane's row among the block's rows by predicted cost, most expensive first (ties: by row number)
+    int rank = lane;
+    if (rpw > 1) {
+        const double cst = (lane < BR && s0 + lane < max_iter) ? row_cost<M, QPL>(prop, lq) : -1.0;   // (rows behind max_iter: last)
+        rank = 0;
+        for (int j = 0; j < BR; ++j) {
+            const double cj = readlane_f64(cst, j);
+            rank += (cj > cst || (cj == cst && j < lane)) ? 1 : 0;
+        }
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
     PIPE_TLX_MARK(pa, t, 1);
     auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
     auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
     auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
     auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
-    int ri = (int)(s0 % N);
-    // row slots of all my rows in one round trip (lane i <-> my row i): the row loop below then starts its loads
+    // row slots of all the block's rows in one round trip (lane l <-> block row l): the row loop below then starts its loads
     // of `old` without waiting for a dependent index load per row
     int my_oslot = 0, my_sslot = 0;
-    if (lane < rpw) {
-        int r = ri + lane; if (r >= N) r -= N;
-        my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + k0 + lane];
+    if (lane < BR) {
+        int r = (int)((s0 + lane) % N);
+        my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + kb0 + lane];
     }
-    // the `old` row of step i + 1 is requested before the row of step i is evaluated: under a full chip an Infinity
-    // Cache / HBM round trip is longer than one sphere row evaluation, one row of lookahead hides it
+    // my i-th row: the block row whose rank is 8 i + v (i even) or 8 i + 7 - v (i odd)
+    auto my_row = [&](int i) {
+        const int target = 8 * i + ((i & 1) ? 7 - wv : wv);
+        const unsigned long long mask = __ballot(lane < BR && rank == target);
+        return (int)__builtin_ctzll(mask | (1ull << 63));          // (every rank 0 .. BR-1 is taken exactly once)
+    };
+    // the `old` row of my next row is requested before the current one is evaluated
     double ocur[QPL], onext[QPL];
+    int lr = my_row(0);
     {
-        const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
+        const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, lr) * qpad + lane;
         PIPE_TLX_MARK(pa, t, 2);
 #pragma unroll
         for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
@@ -1150,48 +1262,51 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     PIPE_PIN_ROW(ocur);                                           // (a pending load carried into the loop would be waited for at its head, every iteration)
     PIPE_TLX_MARK(pa, t, 3);
     for (int i = 0; i < rpw; ++i) {
-        const int k = k0 + i;
-        if (s0 + i >= max_iter) break;
-        const int bl = __builtin_amdgcn_readfirstlane(i);
-        const Contrib<M> cnew = prop.bcast(bl);
-        const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
-        const auto nrow = cache + (size_t)sslot * qpad + lane;
-        const auto dr = dwin + (size_t)k * qpad + lane;
-        double d[QPL], nwv[QPL];
+        const int bl = __builtin_amdgcn_readfirstlane(lr);       // block row of this iteration
+        const int k = kb0 + bl;
+        const int lr_next = i + 1 < rpw ? my_row(i + 1) : lr;
         {
-            const int bn = __builtin_amdgcn_readfirstlane(i + 1 < rpw ? i + 1 : i);
-            const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bn) * qpad + lane;
+            const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, lr_next) * qpad + lane;
 #pragma unroll
             for (int j = 0; j < QPL; ++j) onext[j] = orow[WAVE * j];
         }
-        RowEval<M, QPL>::run(cnew, qt, lane, nwv);
-        PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
-        // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  (Taking the
-        // sums in the scan block's pass over the row instead was measured: its single h pass is the serial part of a
-        // tick, 5x the dot-product work there cost 8 us per tick, here it is spread over every CU.)
-        double s1 = 0., s2 = 0., s3 = 0.;
+        if (s0 + bl < max_iter) {                                 // uniform in the wave (rows behind max_iter rank last)
+            const Contrib<M> cnew = prop.bcast(bl);
+            const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
+            const auto nrow = cache + (size_t)sslot * qpad + lane;
+            const auto dr = dwin + (size_t)k * qpad + lane;
+            double d[QPL], nwv[QPL];
+            RowEval<M, QPL>::run(cnew, qt, lane, nwv);
+            PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
+            // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  (Taking the
+            // sums in the scan block's pass over the row instead was measured: its single h pass is the serial part of a
+            // tick, 5x the dot-product work there cost 8 us per tick, here it is spread over every CU.)
+            double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
-        for (int j = 0; j < QPL; ++j) {
-            const int iq = lane + WAVE * j;
-            nrow[WAVE * j] = nwv[j];
-            d[j] = nwv[j] - ocur[j];
-            dr[WAVE * j] = d[j];
-            const double wd = lw[iq] * d[j];
-            s1 += wd; s2 = fma(lwI[iq], d[j], s2); s3 = fma(wd, d[j], s3);
-        }
-        wave_sum3(s1, s2, s3);
-        if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
-#pragma unroll
-        for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
-            if (p < P) {
-                const double v = readlane_f64(prow[p], bl);
-                if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
+            for (int j = 0; j < QPL; ++j) {
+                const int iq = lane + WAVE * j;
+                nrow[WAVE * j] = nwv[j];
+                d[j] = nwv[j] - ocur[j];
+                dr[WAVE * j] = d[j];
+                const double wd = lw[iq] * d[j];
+                s1 += wd; s2 = fma(lwI[iq], d[j], s2); s3 = fma(wd, d[j], s3);
             }
-        const int ov = __builtin_amdgcn_readlane(pov, bl);
-        if (lane == 0) povf[k] = ov;
+            wave_sum3(s1, s2, s3);
+            if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
+#pragma unroll
+            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+                if (p < P) {
+                    const double v = readlane_f64(prow[p], bl);
+                    if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
+                }
+            const int ov = __builtin_amdgcn_readlane(pov, bl);
+            if (lane == 0) povf[k] = ov;
+        } else {
+            PIPE_PIN_ROW(onext);
+        }
 #pragma unroll
         for (int j = 0; j < QPL; ++j) ocur[j] = onext[j];
-        ri = (ri + 1 == N) ? 0 : ri + 1;
+        lr = lr_next;
     }
     // ---- the sub-window's Gram block from the d rows the block has just written (workgroup-scope visibility:
     // the barrier's fence; same CU, same L1)
@@ -1625,6 +1740,9 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 #endif
         if (lane == 0) {
             store_snap(&pa.chains[rep].snap[t & 1], next);    // read by PROD(t+2) and SCAN(t+1)
+            // a finished chain: the OTHER record's `alive` goes to 0 as well, so that the producers of the odd ticks stop
+            // evaluating rows for it too (one word; a producer of this very launch that still reads 1 only does work nobody uses)
+            if (done) glb(&pa.chains[rep].snap[(t + 1) & 1].alive)[0] = 0;
             ch.SC = SC; ch.SIC = SIC; ch.SCC = SCC; ch.A = cur.A; ch.b = cur.b; ch.chi2 = cur.chi2;
             ch.num_iter = num_iter; ch.num_moves = num_moves; ch.total_steps = total_steps;
             ch.draw_pos = draw_pos; ch.attempts = attempts; ch.converged = converged; ch.stopped = stopped;

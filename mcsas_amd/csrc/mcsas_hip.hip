@@ -334,7 +334,7 @@ struct mcsas_plan {
     SmearDev smear;                     // device copy of the smearing tables (empty when off)
     int qpl = 0, waves = 1, use_cache = 1, dev = 0;
     size_t lds_bytes = 0;
-    double *d_q = nullptr, *d_w = nullptr, *d_wI = nullptr, *d_I = nullptr;
+    double *d_q = nullptr, *d_w = nullptr, *d_wI = nullptr, *d_I = nullptr, *d_q3inv = nullptr;
     double *d_rset = nullptr, *d_cache = nullptr, *d_fit = nullptr, *d_replay = nullptr;
     ChainOut *d_out = nullptr;
     int32_t *h_stop = nullptr;          // pinned + mapped: the kernels poll it
@@ -394,7 +394,7 @@ static void *wg_kernel_for(int model, int qpl) {
 
 extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     if (!pl) return;
-    hipFree(pl->d_q); hipFree(pl->d_w); hipFree(pl->d_wI); hipFree(pl->d_I);
+    hipFree(pl->d_q); hipFree(pl->d_w); hipFree(pl->d_wI); hipFree(pl->d_I); hipFree(pl->d_q3inv);
     hipFree(pl->d_rset); hipFree(pl->d_cache); hipFree(pl->d_fit); hipFree(pl->d_replay); hipFree(pl->d_out);
     if (pl->h_stop) hipHostFree(pl->h_stop);
     if (pl->h_done) hipHostFree(pl->h_done);
@@ -461,7 +461,9 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     rc = pl->smear.upload(p, qpad, &margs);
     if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
     const int tab_shared = table_doubles_host(p->model_id, margs.int_div), tab_row = rowtab_doubles_host(p->model_id, margs.int_div);
-    const bool heavy_rows = tab_shared > 0 || margs.smear_nk > 0;
+    // rows that cost a numerical integration each (2: and whose cost varies with the parameter set — chain_pipe.h, pipe_geometry)
+    const int heavy_rows = (p->model_id == MCSAS_MODEL_KHOLODENKO || p->model_id == MCSAS_MODEL_CYL_ISO) ? 2
+                           : ((tab_shared > 0 || margs.smear_nk > 0) ? 1 : 0);
     int n_cus = 256;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, pl->dev) == hipSuccess && v > 0) n_cus = v; }
 #ifdef MCSAS_TUNING
@@ -526,6 +528,13 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     PCHK(hipMemcpy(pl->d_w, hw.data(), vb, hipMemcpyHostToDevice));
     PCHK(hipMemcpy(pl->d_wI, hwI.data(), vb, hipMemcpyHostToDevice));
     PCHK(hipMemcpy(pl->d_I, hI.data(), vb, hipMemcpyHostToDevice));
+    {   // 1 / q^3 (the branch-free sphere kernel's second reciprocal): the same two multiplications and the same correctly
+        // rounded division the kernels used to make per block
+        std::vector<double> hq3(qpad);
+        for (int i = 0; i < qpad; ++i) hq3[i] = 1.0 / (hq[i] * hq[i] * hq[i]);
+        PCHK(hipMalloc(&pl->d_q3inv, vb));
+        PCHK(hipMemcpy(pl->d_q3inv, hq3.data(), vb, hipMemcpyHostToDevice));
+    }
 
     const size_t R = p->n_reps, N = p->n_contrib, P = p->n_active;
     PCHK(hipMalloc(&pl->d_rset, sizeof(double) * R * N * P));
@@ -667,6 +676,13 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     hot.q = pa.c.q; hot.w = pa.c.w; hot.wI = pa.c.wI; hot.chains = pa.chains;
     hot.n_reps = pa.c.n_reps; hot.n_contrib = pa.c.n_contrib; hot.n_active = pa.c.model.n_active; hot.qpad = pa.c.qpad;
     hot.kb = pa.g.kb; hot.prod_blocks_y = pa.g.prod_blocks_y; hot.w_sub = pa.g.w; hot.max_iter = pa.c.max_iter;
+    hot.q3inv = pl->d_q3inv; hot.sub_per_block = pa.g.sub_per_block;
+    hot.rset = pa.c.rset; hot.cache = pa.c.cache; hot.row_valid = pa.row_valid; hot.cache_rows = pa.c.cache_rows;
+    hot.light_lazy = pa.g.lazy_rows; hot.light = (pa.g.gram_lds || pa.g.overlap) ? 1 : 0;
+    {   // row shares of a SIMD's two producer waves (chain_pipe.h): the LDS variant gives the older wave one row more
+        const int bits = (MCSAS_TUNE_BITS(pl->args) >> 19) & 3;
+        hot.skew = pa.g.gram_lds ? (bits == 0 ? 1 : (bits == 3 ? 0 : bits)) : bits;
+    }
     long long t = -1;                                    // launch t = {SCAN(t), PROD(t+1)}
     for (; t < max_ticks; ++t) {
         if (t >= mcsas_plan::RING && (t % 16) == 0) {
@@ -807,7 +823,6 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
             if (res->draws) res->draws[r] = ho[r].draws;
         }
     }
-    if (ovf & 2) return fail(MCSAS_EHIP, "pipeline: a producer block's row -> Gram hand-off timed out (internal error, results invalid)");
     if (ovf) return fail(MCSAS_ESTREAM, "replay stream exhausted (replay_len=%lld)", (long long)pl->prob.replay_len);
     return MCSAS_OK;
 }

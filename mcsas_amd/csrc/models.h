@@ -718,6 +718,47 @@ template <> struct Contrib<MCSAS_MODEL_LMA_SPHERE> {
     }
 };
 
+// ---------------------------------------------------------------------------------- row cost
+// What one row of a contribution will cost its wave, in arbitrary units, from the parameter set alone — used by the
+// pipeline's producers to hand every wave rows of about the same TOTAL cost (chain_pipe.h, rows with an integral).  Only the
+// order matters; models whose rows all cost the same return 0.  q_lo[j] / q_hi[j]: smallest / largest q of q slot j
+// (the lanes of a wave take the 64 consecutive q of a slot in lockstep: a divergent loop runs to its slowest lane).
+template <int M, int QPL>
+__device__ __forceinline__ double row_cost(const Contrib<M> &c, const double *lq) {
+    if constexpr (M == MCSAS_MODEL_KHOLODENKO) {
+        // panels of 16 quadrature points: oscillatory branch (q > 3 / l_k) ceil(min(x, 2) max(1, F / 8)) + the closed-form tail,
+        // smooth branch 2 + tail (closed form beyond z = 2) or the doubling panels near e = 0
+        double cost = 0.;
+        const double z0 = fmin(c.x, 2.0);
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) {
+            const double qh = lq[WAVE * j + WAVE - 1];
+            if (qh > c.ratio) {
+                const double F = sqrt(fmax(qh * qh * c.lk * c.lk / 9. - 1.0, 0.));
+                cost += ceil(z0 * fmax(1.0, F * 0.125)) + 1.0;
+            } else {
+                cost += 3.0;
+            }
+        }
+        return cost;
+    } else if constexpr (M == MCSAS_MODEL_CYL_ISO) {
+        // per orientation group J1 takes its small-argument form (x <= 5 for every lane), its asymptotic form (x > 5 for every
+        // lane: ~2.3x the instructions) or both; x = q r sqrt(1 - x_k^2) with sqrt(1 - x_k^2) spread over (0, 1)
+        double cost = 0.;
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) {
+            const double ql = lq[WAVE * j], qh = lq[WAVE * j + WAVE - 1];
+            const double tl = 5.0 / (ql * c.r), th = 5.0 / (qh * c.r);
+            const double f_gt = tl < 1.0 ? sqrt(1.0 - tl * tl) : 0.0;            // orientations on the asymptotic form for the whole slot
+            const double f_le = th < 1.0 ? 1.0 - sqrt(1.0 - th * th) : 1.0;      // ... on the small-argument form for the whole slot
+            cost += 144. * f_gt + 64. * f_le + 180. * (1.0 - f_gt - f_le);
+        }
+        return cost;
+    } else {
+        return 0.;
+    }
+}
+
 // ---------------------------------------------------------------------------------- row evaluation
 // out[j] = I(q[lane + 64 j]) for one contribution; the wave-uniform fast/slow choice is made once
 // per row so the QPL evaluations stay in one basic block and interleave.

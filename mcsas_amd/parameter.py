@@ -75,10 +75,10 @@ class Parameter(object):
     def __init__(self, name, value, displayName=None, valueRange=None, **_ignored):
         self._name = name
         self._valueRange = (-np.inf, np.inf)                  # a parameter declared without a range has none
-        if valueRange is not None:
-            self.setValueRange(valueRange)
         self._displayName = displayName or name
         self._value = value
+        if valueRange is not None:
+            self.setValueRange(valueRange)                    # (clips the constructor's value into the range like the reference)
 
     def name(self):
         return self._name
@@ -97,6 +97,10 @@ class Parameter(object):
     def setValueRange(self, newRange):
         # bases/algorithm/parameter.py:420-433: infinities are stored as +-1e200 ("as good as inf")
         self._valueRange = (max(min(newRange), -1e200), min(max(newRange), 1e200))
+        # ... and the current value is brought into the new range (:431-433: setValue(clip()))
+        v = getattr(self, "_value", None)
+        if isinstance(v, (int, float, np.integer, np.floating)) and not isinstance(v, (bool, np.bool_)):
+            self._value = type(v)(np.clip(v, self._valueRange[0], self._valueRange[1])) if isinstance(v, (int, np.integer)) else float(np.clip(v, self._valueRange[0], self._valueRange[1]))
 
     def min(self):
         return self._valueRange[0]

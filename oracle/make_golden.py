@@ -790,6 +790,33 @@ def gen_param_declarations():
     print("G10 written:", ", ".join(out))
 
 
+# ---------------------------------------------------------------- G14 (round 3): long budgets at the BASELINE config-2 shape
+def gen_long_trajectories():
+    """512 q x 400 contributions (config 2's shape) replayed over long budgets, so that the kernels' `ft + (new - old)`
+    and their lazily re-evaluated rows are held against the reference over 60+ sweeps of the contributions, not 4:
+    (a) 25 000 fixed steps; (b) a second data realisation run until the reference itself converges at criterion 2 (a
+    chain that ends by convergence, not by budget).  (With positiveBackground the reference's own trajectory hangs on where
+    MINPACK stalls next to the |b| kink — it hit maxfev on this very chain — so (b) keeps the default free background.)"""
+    q_nm, I, sig = synthetic_sphere_data(512)
+    d = sasdata(q_nm, I, sig)
+    dv = data_vectors(d)
+    m = Sphere(); m.radius.setActiveRange((np.pi / dv["q"].max(), np.pi / dv["q"].min()))
+    algo = new_algo(numContribs=400, numReps=1, maxIterations=25000, convergenceCriterion=1e-9)
+    algo.model = m; algo.data = d
+    spec = dict(model="sphere", n_contrib=400, lo=[min(m.radius.activeRange())], hi=[max(m.radius.activeRange())], gen=[0],
+                comp_exp=0.6666666, max_iter=25000, conv_crit=1e-9, sld=m.sld())
+    save_traj("g14_sphere_q512_long.npz", dv, spec, run_mcfit(algo, 400, 1401))
+    q_nm, I, sig = synthetic_sphere_data(512, seed=77)
+    d2 = sasdata(q_nm, I, 2.0 * sig)                          # twice the uncertainty: the chain gets to chi2 <= 2 in ~1e4 steps
+    dv2 = data_vectors(d2)
+    m2 = Sphere(); m2.radius.setActiveRange((np.pi / dv2["q"].max(), np.pi / dv2["q"].min()))
+    algo = new_algo(numContribs=400, numReps=1, maxIterations=100000, convergenceCriterion=2.0)
+    algo.model = m2; algo.data = d2
+    spec2 = dict(spec); spec2.update(lo=[min(m2.radius.activeRange())], hi=[max(m2.radius.activeRange())], max_iter=100000,
+                                     conv_crit=2.0)
+    save_traj("g14_sphere_q512_converge.npz", dv2, spec2, run_mcfit(algo, 400, 1402))
+
+
 # ---------------------------------------------------------------- G13 (round 3): the quick-start fit, free-running
 def gen_quickstart(seed=3001):
     """doc/source/quickstart.rst:66-107: Sphere on testdata/quickstartdemo1.csv, radius range from the data
@@ -854,3 +881,5 @@ if __name__ == "__main__":
         gen_kholodenko_config5()
     if "quickstart" in which or not sys.argv[1:]:
         gen_quickstart()
+    if "long" in which or not sys.argv[1:]:
+        gen_long_trajectories()

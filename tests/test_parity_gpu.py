@@ -62,7 +62,10 @@ TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q5
         # round 2: reference replays at the BASELINE shapes of configs 3 and 4 (512 q x 400 cylinders, 2000 steps;
         # 1024 q x 1000 core-shell ellipsoids, 1500 steps), a 64 q x 64 x 300-step Kholodenko chain on the
         # reference's worm data file, and config 5 AS NAMED (that file at 512 q x 600 contributions, 300 steps)
-        "g9_cyl_q512.npz", "g9_ellcs_q1024.npz", "g9_kho_q64.npz", "g9_kho_q512.npz"]
+        "g9_cyl_q512.npz", "g9_ellcs_q1024.npz", "g9_kho_q64.npz", "g9_kho_q512.npz",
+        # round 3: config 2's shape (512 q x 400) over long budgets — 25 000 fixed steps (62 sweeps over the contributions) and a
+        # chain that the reference ends by convergence (criterion 2, 5509 steps)
+        "g14_sphere_q512_long.npz", "g14_sphere_q512_converge.npz"]
 
 
 @pytest.mark.parametrize("name", TRAJ)
@@ -639,6 +642,99 @@ def test_kholodenko_regimes_vs_quadpack():
         np.testing.assert_allclose(got, ref, rtol=2e-9)
 
 
+def test_kholodenko_active_ranges_vs_quadpack_500_sets():
+    """The worm-like chain form factor over the model's whole preset active range (models/kholodenko.py:57-71: radius 1-5 nm,
+    Kuhn length 10-50 nm, contour length 100-1000 nm; the box's corners and edges included) against the oracle's QUADPACK
+    evaluation (models/kholodenko.py:32-49, epsrel 1e-10): 500 seeded parameter sets x 32 q on the q range of the reference's
+    worm data file, relative difference <= 2e-9 everywhere."""
+    rs = np.random.RandomState(2025)
+    lo, hi = np.array([1e-9, 1e-8, 1e-7]), np.array([5e-9, 5e-8, 1e-6])
+    sets = lo + (hi - lo) * rs.uniform(size=(500, 3))
+    corners = np.array([[(lo, hi)[(c >> k) & 1][k] for k in range(3)] for c in range(8)])
+    sets[:8] = corners
+    for k in range(3):                                        # edge mid-points: one coordinate free, the others at a bound
+        for c in range(4):
+            e = np.array([(lo, hi)[(c >> j) & 1][(k + 1 + j) % 3] for j in range(2)])
+            row = np.empty(3); row[k] = 0.5 * (lo[k] + hi[k]); row[(k + 1) % 3] = e[0]; row[(k + 2) % 3] = e[1]
+            sets[8 + 4 * k + c] = row
+    m, spec = make_models("kholodenko", lo, hi)
+    g = load("g9_kho_q512.npz")
+    qlo, qhi = g["data_q"].min(), g["data_q"].max()
+    beyond = []
+    for i in range(0, 500, 50):
+        q = np.sort(qlo * (qhi / qlo) ** rs.uniform(size=32))
+        got = engine.model_calc(m.setup(), q, sets[i:i + 50], 0.6666666, want_rows=True)[4]
+        for j in range(50):
+            ref = O.calc_intensity(spec, q, sets[i + j], 0.6666666)[0]
+            rel = np.abs(got[j] / ref - 1)
+            np.testing.assert_allclose(got[j], ref, rtol=2e-8, err_msg="set %d %r" % (i + j, sets[i + j]))
+            beyond += [(i + j, float(q[k]), float(got[j][k])) for k in np.nonzero(rel > 2e-9)[0]]
+    # QUADPACK at epsrel 1e-10 is itself off by a few 1e-9 at a handful of the 16 000 points (deep in the oscillating tail,
+    # five decades below the forward intensity; first seen at set 140, q = 6.24e9 1/m: +2.66e-9).  Every point where the
+    # two disagree by more than 2e-9 is settled against a 30-digit evaluation of the same integral: the kernel is the one
+    # that is right, to 1e-10.
+    assert len(beyond) <= 16, len(beyond)
+    for idx, qq, val in beyond:
+        np.testing.assert_allclose(val, _kholodenko_mp(qq, sets[idx], 0.6666666), rtol=1e-10, err_msg="set %d q %g" % (idx, qq))
+
+
+def _kholodenko_mp(q, row, comp_exp):
+    """models/kholodenko.py:16-94 in 30-digit arithmetic (mpmath): intensity F^2 V^(2c) of one worm at one q."""
+    import mpmath as mp
+    mp.mp.dps = 30
+    r, lk, lc = [mp.mpf(float(v)) for v in row]
+    q = mp.mpf(float(q))
+    x = 3 * lc / lk
+    if q > 3 / lk:
+        F = mp.sqrt(q * q * lk * lk / 9 - 1)
+        f = lambda z: mp.sin(F * z) / (F * mp.sinh(z)) if z != 0 else mp.mpf(1)
+    else:
+        e = mp.sqrt(1 - q * q * lk * lk / 9)
+        f = (lambda z: mp.sinh(e * z) / (e * mp.sinh(z)) if z != 0 else mp.mpf(1)) if e != 0 else (lambda z: z / mp.sinh(z) if z != 0 else mp.mpf(1))
+    pts = sorted(set([mp.mpf(0)] + [mp.mpf(k) for k in (1, 2, 4, 8, 16, 32, 64, 128) if k < x] + [x]))
+    p0 = mp.quad(lambda z: f(z) * (2 / x) * (1 - z / x), pts, maxdegree=10)
+    u = q * r
+    pcs = 2 * mp.besselj(1, u) / u
+    vol = mp.pi * lc * r * r
+    return float(p0 * pcs * pcs * vol ** (2 * mp.mpf(comp_exp)))
+
+
+def test_cylinders_at_the_ends_of_the_aspect_range():
+    """Isotropic cylinders at aspect 1e-3 and 1e3, the ends of the parameter's value range (models/cylindersisotropic.py:31-36),
+    and radii from 0.1 nm (its lower bound) to 100 nm: needles and discs against the oracle's trapezoid over scipy's j1."""
+    m, spec = make_models("cyl_aspect", [1e-10, 1e-3], [1e-7, 1e3])
+    q = np.logspace(7, np.log10(3e9), 48)
+    rows = np.array([[r, asp] for r in (1e-10, 1e-9, 7.3e-9, 4e-8, 1e-7) for asp in (1e-3, 3.3e-2, 1.0, 47.0, 1e3)])
+    got = engine.model_calc(m.setup(FakeData(q)), q, rows, 0.6666666, want_rows=True)[4]
+    for j, row in enumerate(rows):
+        ref = O.calc_intensity(spec, q, row, 0.6666666)[0]
+        np.testing.assert_allclose(got[j], ref, rtol=1e-9, atol=1e-14 * ref.max(), err_msg=repr(row))
+
+
+def test_lazy_rows_equal_eager_rows_over_a_long_free_run():
+    """The lazy row cache's premise — a contribution row evaluated again for the cache (one q per thread, intensity_fast)
+    has the bits of the row evaluated as a proposal (eight q per lane interleaved, intensity_fast_n) — over a long
+    free-running run at config 2's shape: 50 repetitions x 20 000 steps with the device's Philox stream, default (lazy) on
+    the release library against the eager variant of the measurement build (every `new` row stored, row slots swapped on
+    acceptance; same Gram grouping, so the two must agree to the last bit), and against equal row shares of a SIMD's two
+    producer waves (arithmetic does not depend on which wave evaluates a row)."""
+    from bench import synthetic_data
+    q, I, sig = synthetic_data(512)
+    m = mcsas_amd.Sphere(); m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
+    runs = []
+    for flags in (0, 1 << 16, 3 << 19):
+        st = engine.Settings(n_contrib=400, n_reps=50, max_iter=20000, conv_crit=0.0, max_retries=0, seed=99,
+                             exec_mode=engine.EXEC_PIPELINE, debug_flags=flags)
+        runs.append(engine.analyse(m.setup(), q, I, sig, st))
+    assert runs[0].num_moves.min() > 800
+    for other in runs[1:]:
+        np.testing.assert_array_equal(other.contribs, runs[0].contribs)
+        np.testing.assert_array_equal(other.num_moves, runs[0].num_moves)
+        np.testing.assert_array_equal(other.chisq, runs[0].chisq)
+        np.testing.assert_array_equal(other.fit, runs[0].fit)
+
+
+
 RANDOM_RANGES = {   # generator ranges per model tag (SI)
     "sphere": ([2e-9], [3e-7]), "cyl_aspect": ([1e-9, 0.5], [1e-7, 20.0]), "cyl_length": ([1e-9, 5e-9], [1e-7, 5e-7]),
     "ellcs": ([1e-9, 2e-9, 2e-10], [1e-7, 2e-7, 1e-8]), "kholodenko": ([1e-9, 1e-8, 1e-7], [5e-9, 5e-8, 1e-6]),
@@ -857,7 +953,10 @@ def test_pipeline_geometry_follows_the_chain_count():
     (the window stays 192 steps at 512 q x 400 contributions: 3 / 4 / 6 rows per producer wave), rows with an integral
     the number of producer blocks that gives the most steps per round of CUs.  Pinned here on a 256-CU MI355X."""
     import mcsas_amd
+    import torch
     from bench import synthetic_data
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the expected windows are those of a 256-CU device (the library reads the CU count at run time)")
     q, I, sig = synthetic_data(512)
     m = mcsas_amd.Sphere()
     m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
