@@ -119,13 +119,8 @@ struct PipeArgs {
 struct PipeHot {
     const double *q, *w, *wI, *q3inv;                          // q3inv = 1 / q^3, host-made (the same IEEE operations as on the device)
     PipeChain *chains;
-    int32_t n_reps, n_contrib, n_active, qpad, kb, prod_blocks_y, w_sub, sub_per_block;
+    int32_t n_reps, n_contrib, n_active, qpad, kb, prod_blocks_y, w_sub, pad;
     int64_t max_iter;
-    // rows without an integral, lazy row cache: what a producer block asks memory for before it has seen its chain's
-    // schedule record (speculating on attempt 0)
-    double *rset, *cache;
-    int32_t *row_valid;
-    int32_t cache_rows, light_lazy, skew, light;               // light: rows without an integral on the LDS / overlapped producer
 };
 
 // schedule records go through scalar global loads / stores (a struct copy out of an address-space-qualified
@@ -748,97 +743,8 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         const int i = tid + PIPE_BLOCK * x < qpad ? tid + PIPE_BLOCK * x : 0;
         tq[x] = glb(hot.q)[i]; tw[x] = glb(hot.w)[i]; twI[x] = glb(hot.wI)[i]; tq3[x] = glb(hot.q3inv)[i];
     }
-    // ---- rows without an integral, lazy row cache: the `old` side of my rows — validity flags, parameter sets and the first
-    // `old` row — is requested NOW, beside the tables and the schedule record, on the guess that the chain is in its first
-    // attempt (t_init = 0); a chain that has been restarted asks again once the record is here (one more round trip)
-    struct RowShare { int W, nsb, BR, RW, rbase, nmine; };
-    RowShare rs_{};
-    int sp_valid = 1, sp_r = -1;                              // speculative: flag and contribution of lane 32 + l's row l
-    double sp_prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
-    double sp_ocur[QPL];
-#pragma unroll
-    for (int j = 0; j < QPL; ++j) sp_ocur[j] = 0.;
-    int64_t sb0_guess = -1;
-    const int wv0 = __builtin_amdgcn_readfirstlane(wave);
-    auto old_side = [&](int64_t sb0, int &v, int &r_out, double (&pr)[MCSAS_MAX_ACTIVE], double (&oc)[QPL]) {
-        const int l2 = lane - 32;
-        v = 1; r_out = -1;
-        if (l2 >= 0 && l2 < rs_.nmine) {
-            const int lrow_o = (l2 / rs_.RW) * rs_.W + rs_.rbase + (l2 % rs_.RW);
-            if (sb0 + lrow_o < max_iter) {
-                const int r = (int)((sb0 + lrow_o) % N);
-                r_out = r;
-                v = glb(hot.row_valid)[(size_t)rep * N + r];
-#pragma unroll
-                for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) if (p < P) pr[p] = glb(hot.rset)[((size_t)rep * N + r) * P + p];
-            }
-        }
-        const int r0 = (int)((sb0 + rs_.rbase) % N);          // my first row's contribution (its row slot: lazy rows never move)
-        const auto orow0 = glb(hot.cache) + ((size_t)rep * hot.cache_rows + r0) * qpad + lane;
-#pragma unroll
-        for (int j = 0; j < QPL; ++j) oc[j] = orow0[WAVE * j];
-    };
-    // Rows per wave and sub-window: W / 8 on average, the four waves that share their SIMDs with an older wave (4-7) give
-    // `skew` rows to the older ones (0-3) (host: 1 for the LDS variant — the SIMD arbitrates oldest-first, so with equal
-    // shares the older wave is done early and the younger one finishes the phase alone, latency-bound: measured 4 + 2 rows
-    // 3.92 ms, 3 + 3 4.03, 5 + 1 4.2)
-    if constexpr (pipe_light_model(M)) if (hot.light) {
-        const int W = hot.w_sub, rw_even = W >> 3, skew = hot.skew < rw_even ? hot.skew : rw_even - 1;
-        rs_.W = W; rs_.nsb = hot.sub_per_block; rs_.BR = rs_.nsb * W;
-        rs_.RW = wv0 < 4 ? rw_even + skew : rw_even - skew;                           // my rows per sub-window
-        rs_.rbase = wv0 < 4 ? wv0 * (rw_even + skew) : 4 * (rw_even + skew) + (wv0 - 4) * (rw_even - skew);   // my first row in a sub-window
-        rs_.nmine = rs_.nsb * rs_.RW;
-        if (hot.light_lazy && t >= 1) {
-            sb0_guess = ((int64_t)t - 1) * Kb + (int64_t)by * rs_.BR;
-            old_side(sb0_guess, sp_valid, sp_r, sp_prow, sp_ocur);
-        }
-    }
     const PipeSnap sn = load_snap(&hot.chains[rep].snap[t & 1]);
     if (!sn.alive || t < sn.t_init) return;
-
-    // ---- rows without an integral, a window tick: the proposals of my rows (lane l <-> my l-th row; random stream, generator
-    // transform) and ONE prepare() for them and for the `old` parameter sets of the mirror lanes 32 + l — worked out HERE, while
-    // the tables are still on their way: nothing in it needs them
-    struct LightPre { double prow[MCSAS_MAX_ACTIVE]; Contrib<M> prop; int pov, my_oslot, my_sslot, stale_r; bool old_lane; };
-    LightPre lp_{};
-    const bool light_win = pipe_light_model(M) && hot.light && t > sn.t_init && !(MCSAS_TUNE_BITS(a) & 16);
-    if constexpr (pipe_light_model(M)) if (light_win) {
-        const int W = rs_.W, BR = rs_.BR, RW = rs_.RW, rbase = rs_.rbase, nmine = rs_.nmine, buf = t & 1;
-        const bool lazy = hot.light_lazy;
-        const int64_t sb0 = ((int64_t)t - sn.t_init - 1) * Kb + (int64_t)by * BR;      // global step of the block's first row
-        const int lrow = (lane / RW) * W + rbase + (lane % RW);                        // my lane's row: its offset in the block
-        const int l2 = lane - 32;
-        lp_.old_lane = lazy && l2 >= 0 && l2 < nmine;
-        if (lazy && sb0 != sb0_guess) old_side(sb0, sp_valid, sp_r, sp_prow, sp_ocur);   // (a restarted chain, or tick 0)
-        lp_.stale_r = -1; lp_.pov = 0; lp_.my_oslot = 0; lp_.my_sslot = 0;
-#pragma unroll
-        for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) lp_.prow[p] = 0.;
-        if (lp_.old_lane && sp_r >= 0) {
-#pragma unroll
-            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) lp_.prow[p] = sp_prow[p];
-            if (!sp_valid) lp_.stale_r = sp_r;
-        }
-        const DrawSource src{a.replay ? a.replay + (size_t)rep * a.replay_len : nullptr, a.replay_len, a.seed,
-                             (uint32_t)(a.rep_offset + rep)};
-        const int r = (int)((sb0 + lrow) % N);
-        if (lane < nmine) {
-            if (lazy) lp_.my_oslot = r;
-            else {
-                lp_.my_oslot = glb(pa.slot_of)[(size_t)rep * N + r];
-                lp_.my_sslot = glb(pa.stage_slot)[(size_t)rep * 2 * Kb + buf * Kb + by * BR + lrow];
-            }
-        }
-        const int64_t sl = sb0 + lrow;
-#pragma unroll
-        for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
-            if (p < P) {
-                double u = 0.5;
-                if (lane < nmine && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, lp_.pov);
-                const double pv = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
-                if (!(lp_.old_lane && sp_r >= 0)) lp_.prow[p] = pv;
-            }
-        lp_.prop.prepare(a.model, lp_.prow);
-    }
 
     double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
 #pragma unroll
@@ -900,13 +806,28 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     }
 
     if (MCSAS_TUNE_BITS(a) & 16) return;                                  // diagnostic: no window rows
-    if constexpr (pipe_light_model(M)) if (hot.light) {           // (rows with an integral never take this path: not instantiated for them)
-        // ---- rows without an integral.  The block's rows are nsb sub-windows of W steps, every wave its share of each
-        // (rs_); d = new - old goes to the window buffer, the sub-window's Gram block is taken with fp64 MFMAs.  Default (LDS
-        // variant): rows of a sub-window, barrier, Gram block from the LDS copy of its d rows, next sub-window.  Measurement
-        // builds also carry the overlapped variant (Gram units of sub-window s between the rows of s + 1, operands read back
-        // from the window buffer in HBM/L2): see rows_and_gram below.
-        const int W = rs_.W, nsb = rs_.nsb, BR = rs_.BR, RW = rs_.RW, rbase = rs_.rbase, nmine = rs_.nmine, wv = wv0;
+    if constexpr (pipe_light_model(M)) if (pa.g.overlap || pa.g.gram_lds) {   // (rows with an integral never take this path: not instantiated for them)
+        // ---- overlapped producer.  The block's rows are nsb sub-windows of W; phase ss = the rows of sub-window ss, every
+        // wave its share, d = new - old straight to the window buffer.  The Gram block of sub-window ss - 1 is worked off
+        // in units BETWEEN the rows of phase ss (matrix pipe beside the vector pipe: while one wave of a SIMD is inside a run
+        // of MFMAs its partner has the vector issue slots to itself), its operands read back from the window buffer.
+        // One barrier per phase, and it waits for no memory: a wave passes B(ss - 1) — "the rows of ss - 1 are visible to the
+        // workgroup" — behind its FIRST row of phase ss, after a counted wait that covers exactly its stores of phase
+        // ss - 1 (the counter is in order: everything older than that row's own stores has completed by then).  The partial
+        // tiles of a block are parked in LDS when a wave has done its last unit and summed by all threads behind the next
+        // barrier (two reduction buffers, by parity).  Only the last sub-window's Gram block runs with nothing beside it.
+        const int W = pa.g.w, nsb = pa.g.sub_per_block, BR = nsb * W;
+        // Rows per wave and sub-window: W / 8 on average; tuning bits 19-20 shift rows from the four waves that share
+        // their SIMDs with an older wave (4-7) to the older ones (0-3): 0 = equal shares, 1 / 2 = one / two rows.
+        // (the LDS variant's default is one row: the SIMD arbitrates oldest-first, so with equal shares the older wave is done
+        // early and the younger one finishes the phase alone, latency-bound — measured 4 + 2 rows 3.92 ms, 3 + 3 4.03, 5 + 1 4.2;
+        // bits 19-20 = 3 there: equal shares)
+        const int rw_even = W >> 3, skew_bits = (MCSAS_TUNE_BITS(a) >> 19) & 3;
+        const int skew_req = pa.g.gram_lds ? (skew_bits == 0 ? 1 : (skew_bits == 3 ? 0 : skew_bits)) : skew_bits;
+        const int skew = skew_req < rw_even ? skew_req : rw_even - 1;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int RW = wv < 4 ? rw_even + skew : rw_even - skew;                        // my rows per sub-window
+        const int rbase = wv < 4 ? wv * (rw_even + skew) : 4 * (rw_even + skew) + (wv - 4) * (rw_even - skew);   // my first row in a sub-window
         const int buf = t & 1;
         const int64_t w = (int64_t)t - sn.t_init - 1;
         const int64_t sb0 = w * Kb + (int64_t)by * BR;                                 // global step of the block's first row
@@ -915,45 +836,68 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
         auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
         auto gwin = glb(pa.gwin) + ((size_t)rep * 2 + buf) * Kb * W;
-        double *gred = lds + pa.g.gram_off + 16;                                       // Gram reduction buffer (the stale-row hand-over uses it first)
+        double *gred = lds + pa.g.gram_off + 16;                                       // [2][8 waves][PIPE_GRAM_NT_MAX][256]
         constexpr size_t GRED = (size_t)PIPE_WAVES * PIPE_GRAM_NT_MAX * 256;
+        const int nmine = nsb * RW;                                                    // my rows (<= 8), lane l <-> my l-th row
         const bool no_gram = MCSAS_TUNE_BITS(a) & 64;                                              // diagnostic: no Gram blocks (uniform)
         const int lrow = (lane / RW) * W + rbase + (lane % RW);                        // its offset in the block
-        const bool lazy = hot.light_lazy;
+        const bool lazy = pa.g.lazy_rows;
         PIPE_TLX_MARK(pa, t, 0);
         // ---- lazy rows: the block's stale `old` rows (their last proposal, N steps ago, was accepted: ~6 % of them) are
         // evaluated again from the parameter set, one q per thread and row — an eighth of a wave's row time for the whole
         // block, and no wave ends up with more rows than the others — and written back to the row cache.  Lanes 32 + l of
-        // a wave mirror its lanes l: the same rows, their `old` side — validity flag and parameter set (requested at the
-        // block's entry); the proposals and the Contrib records of both were prepared before the tables' barrier (lp_).
+        // a wave mirror its lanes l: the same rows, their `old` side — validity flag and parameter set in one round trip
+        // (under way while the proposals are drawn), and ONE prepare() call serves the proposals and the old sets.
         constexpr int CON = 12;                                   // doubles per Contrib record in LDS
         static_assert(sizeof(Contrib<M>) <= 8 * CON && sizeof(Contrib<M>) % 8 == 0, "Contrib record");
         int32_t *stl = reinterpret_cast<int32_t *>(gred);         // [0] count (zeroed before the tables' barrier), then the stale contributions
-        double *scon = gred + 64;                                 // their Contrib records (up to 64)
-        double *stash = gred + 1024;                              // the refreshed rows themselves, for the rows of the first sub-window
-        const int stash_cap = (PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256 - 1024) / qpad;   // (the smallest reduction buffer: 32 KB)
-        double (&prow)[MCSAS_MAX_ACTIVE] = lp_.prow;
-        const Contrib<M> &prop = lp_.prop;
-        const int pov = lp_.pov, my_oslot = lp_.my_oslot, my_sslot = lp_.my_sslot, stale_r = lp_.stale_r;
+        double *scon = gred + 64;                                 // their Contrib records
+        double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+        const int l2 = lane - 32;
+        const bool old_lane = lazy && l2 >= 0 && l2 < nmine;
+        int stale_r = -1;
+        if (old_lane) {
+            const int lrow_o = (l2 / RW) * W + rbase + (l2 % RW);
+            if (sb0 + lrow_o < max_iter) {
+                const int r = (int)((sb0 + lrow_o) % N);
+                const int v = row_valid[r];
+#pragma unroll
+                for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) if (p < P) prow[p] = rset[(size_t)r * P + p];
+                if (!v) stale_r = r;
+            }
+        }
+        int pov = 0, my_oslot = 0, my_sslot = 0;
+        {
+            const int r = (int)((sb0 + lrow) % N);
+            if (lane < nmine) {
+                if (lazy) my_oslot = r;
+                else { my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + by * BR + lrow]; }
+            }
+            const int64_t sl = sb0 + lrow;
+#pragma unroll
+            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+                if (p < P) {
+                    double u = 0.5;
+                    if (lane < nmine && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
+                    const double pv = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
+                    if (!(old_lane && sb0 + ((l2 / RW) * W + rbase + (l2 % RW)) < max_iter)) prow[p] = pv;
+                }
+        }
+        Contrib<M> prop;
+        prop.prepare(a.model, prow);
         PIPE_TLX_MARK(pa, t, 1);
-        // my_stash (lanes 32 + l): >= 0 = row l's `old` row is stale and its fresh copy sits in stash row my_stash
-        int my_stash = -1;
-        bool stash_ok = true;
+        int nst = 0;
         if (lazy) {
             if (stale_r >= 0) {
                 const int e = atomicAdd(&stl[0], 1);
-                if (e < 64) {
-                    stl[1 + e] = stale_r;
-                    double tmp[CON] = {};
-                    __builtin_memcpy(tmp, &prop, sizeof(Contrib<M>));
+                stl[1 + e] = stale_r;
+                double tmp[CON] = {};
+                __builtin_memcpy(tmp, &prop, sizeof(Contrib<M>));
 #pragma unroll
-                    for (int i = 0; i < (int)(sizeof(Contrib<M>) / 8); ++i) scon[e * CON + i] = tmp[i];
-                }
-                my_stash = e;
+                for (int i = 0; i < (int)(sizeof(Contrib<M>) / 8); ++i) scon[e * CON + i] = tmp[i];
             }
             PIPE_LDS_BARRIER();
-            const int nst = stl[0];                               // (<= 64: a block has at most 64 rows)
-            stash_ok = pa.g.gram_lds && nst <= stash_cap;         // uniform in the block (the overlapped variant of a measurement build: never)
+            nst = stl[0];
             for (int i = 0; i < nst; ++i) {                       // (list order varies from run to run, the rows do not depend on it)
                 const int r = stl[1 + i];
                 Contrib<M> c;
@@ -966,19 +910,12 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
 #pragma unroll
                 for (int x = 0; x < QTB; ++x) {
                     const int iq = tid + PIPE_BLOCK * x;
-                    if (iq < qpad) {
-                        const double v = pipe_point_intensity<M>(c, lq[iq], lq3[iq], tab);
-                        cache[(size_t)r * qpad + iq] = v;
-                        if (stash_ok) stash[(size_t)i * qpad + iq] = v;
-                    }
+                    if (iq < qpad) cache[(size_t)r * qpad + iq] = pipe_point_intensity<M>(c, lq[iq], lq3[iq], tab);
                 }
                 if (tid == 0) row_valid[r] = 1;
             }
-            // The fresh rows reach the waves that need them as `old` through LDS (first sub-window) — no wait for the stores, no
-            // second trip to memory — or, past the first sub-window's barrier, from the row cache (every storing wave has waited
-            // for its loads, hence for these older stores, in its first row).  More stale rows than the hand-over buffer holds
-            // (never seen at ~6 % acceptance): the stores are waited for and everything comes from the row cache.
-            if (nst) { if (stash_ok) PIPE_LDS_BARRIER(); else __syncthreads(); }
+            if (nst) __syncthreads();                             // the refreshed rows have landed before the row loop loads them (uniform)
+            else PIPE_LDS_BARRIER();                              // (the stale list shares the reduction buffer: read by all before it is reused)
         }
         PIPE_TLX_MARK(pa, t, 2);
         PIPE_TLX_MARK(pa, t, 3);
@@ -1000,10 +937,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
             const int dstr = qpad + PIPE_DROW_PAD;
             double *dbuf = lds + pa.g.drow_off;
             double ocur[QPL], onext[QPL];
-            if (lazy) {
-#pragma unroll
-                for (int j = 0; j < QPL; ++j) ocur[j] = sp_ocur[j];                   // requested at the block's entry
-            } else {
+            {
                 const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, 0) * qpad + lane;
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
@@ -1029,22 +963,6 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                     double *dl = dbuf + (size_t)(rbase + jr) * dstr + lane;
                     RowEval<M, QPL>::run(cnew, qt, lane, nwv);
                     PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
-                    // a stale `old` row was evaluated again at the block's start: what memory returned for it may predate that
-                    const int e_l = __builtin_amdgcn_readlane(my_stash, 32 + bl);
-                    if (e_l >= 0) {                                                 // uniform in the wave, ~6 % of the rows
-                        if (ss == 0 && stash_ok) {
-                            const double *srow = stash + (size_t)e_l * qpad + lane;
-#pragma unroll
-                            for (int j = 0; j < QPL; ++j) ocur[j] = srow[WAVE * j];
-                        } else if (jr == 0) {
-                            // requested before the barrier behind which the fresh row is visible in the row cache (a later
-                            // sub-window's first row; or the block's first row when the hand-over buffer was too small)
-                            const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bl) * qpad + lane;
-#pragma unroll
-                            for (int j = 0; j < QPL; ++j) ocur[j] = orow[WAVE * j];
-                            PIPE_PIN_ROW(ocur);
-                        }
-                    }
                     double s1 = 0., s2 = 0.;
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) {

@@ -16,6 +16,7 @@
 #include "chain_common.h"
 #include "chain_wg.h"   // WgGeom / wg_geometry only; the kernels are instantiated in kern_*.hip
 #include "chain_pipe.h" // PipeArgs / pipe_geometry only
+#include "auto_table.h" // measured rates of the execution modes (tools/make_auto_table.py)
 
 using namespace mcsas;
 
@@ -411,6 +412,29 @@ extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     delete pl;
 }
 
+// MCSAS_EXEC_AUTO, rows without an integral: nearest swept shape in (log q slots, log contributions), rates interpolated
+// linearly in the repetition count, modes that cannot run the shape left out
+static int auto_mode_light(int qpad, int n_contrib, double reps, bool pipe_ok, bool wg_ok) {
+    if (reps < (double)auto_reps[0]) return pipe_ok ? MCSAS_EXEC_PIPELINE : (wg_ok ? MCSAS_EXEC_WORKGROUP : MCSAS_EXEC_WAVE);
+    int iq = 0, in = 0;
+    for (int i = 1; i < AUTO_NQ; ++i) if (std::fabs(std::log((double)qpad / auto_qpad[i])) < std::fabs(std::log((double)qpad / auto_qpad[iq]))) iq = i;
+    for (int i = 1; i < AUTO_NN; ++i) if (std::fabs(std::log((double)n_contrib / auto_ncontrib[i])) < std::fabs(std::log((double)n_contrib / auto_ncontrib[in]))) in = i;
+    int ir = 0;
+    while (ir + 2 < AUTO_NR && reps >= (double)auto_reps[ir + 1]) ++ir;
+    double f = (reps - auto_reps[ir]) / (double)(auto_reps[ir + 1] - auto_reps[ir]);
+    f = f < 0. ? 0. : (f > 1. ? 1. : f);
+    const float (&a)[3] = auto_rate[iq][in][ir], (&b)[3] = auto_rate[iq][in][ir + 1];
+    const bool ok[3] = {true, wg_ok, pipe_ok};
+    static const int modes[3] = {MCSAS_EXEC_WAVE, MCSAS_EXEC_WORKGROUP, MCSAS_EXEC_PIPELINE};
+    int best = 0; double best_rate = -1.;
+    for (int m = 0; m < 3; ++m) {
+        if (!ok[m] || a[m] <= 0.f || b[m] <= 0.f) continue;
+        const double r = a[m] + f * (b[m] - a[m]);
+        if (r > best_rate) { best_rate = r; best = m; }
+    }
+    return modes[best];
+}
+
 extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     if (!p || !out) return fail(MCSAS_EINVAL, "null argument");
     *out = nullptr;
@@ -486,18 +510,25 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         else if (waves > 1) mode = MCSAS_EXEC_WORKGROUP;
         else {
             PipeGeom pg; WgGeom wgm;
-            // measured crossovers (tools/mode_sweep.py, sphere 512 q x 400, round 2: pipeline 2.4-2.6e8 steps/s up to
-            // 128 chains, workgroup per chain 2.4 / 2.9 / 3.3e8 at 128 / 192 / 256, wavefront per chain 2.4 / 3.1 / 4.7e8
-            // at 384 / 512 / 1024): the pipeline up to 128 chains, one workgroup per chain below 384, one wavefront per
-            // chain from there; rows that cost an integral each keep the workgroup's seven producer waves per chain
-            // until the chains alone fill the SIMDs (tools/mode_sweep_heavy.py: cylinders 5.1-5.4e6 steps/s in the pipeline at
-            // any chain count, 3.7 / 5.1 / 5.0e6 per workgroup at 192 / 256 / 512 chains; Kholodenko 3.3-3.5e6 in the
-            // pipeline, 3.2 / 4.3 / 4.3e6 per workgroup, 4.0 / 5.2e6 per wavefront at 1024 / 2048: its row cost varies with
-            // the proposal, which a tick's barrier pays for and independent workgroups average out)
-            if (p->n_reps >= (heavy_rows ? 1024 : 384)) mode = MCSAS_EXEC_WAVE;
-            else if (p->n_reps <= (heavy_rows ? 192 : 128) && pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pg) == 0) mode = MCSAS_EXEC_PIPELINE;
-            else if (wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0) mode = MCSAS_EXEC_WORKGROUP;
-            else mode = MCSAS_EXEC_WAVE;
+            const bool pipe_ok = pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pg) == 0;
+            const bool wg_ok = !wide_q && wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0;
+            if (!heavy_rows) {
+                // rows without an integral: the mode with the highest MEASURED rate at the nearest swept shape
+                // (auto_table.h: 128..1024 q slots x 200..1000 contributions x 64..3000 repetitions on a 256-CU MI355X;
+                // profiles/r03_mode_sweep*.jsonl).  Fewer than 64 chains: the pipeline wins at every swept shape (1, 10, 50
+                // repetitions).  A device with another CU count is asked at the repetition count that loads it the same.
+                mode = auto_mode_light(qpad, p->n_contrib, (double)p->n_reps * 256.0 / (double)n_cus, pipe_ok, wg_ok);
+            } else {
+                // rows that cost an integral each keep the workgroup's seven producer waves per chain until the chains alone
+                // fill the SIMDs (round 2, tools/mode_sweep_heavy.py: cylinders 5.1-5.4e6 steps/s in the pipeline at any chain
+                // count, 3.7 / 5.1 / 5.0e6 per workgroup at 192 / 256 / 512 chains; Kholodenko 3.3-3.5e6 in the pipeline,
+                // 3.2 / 4.3 / 4.3e6 per workgroup, 4.0 / 5.2e6 per wavefront at 1024 / 2048); thresholds in units of a 256-CU device
+                const double r_eff = (double)p->n_reps * 256.0 / (double)n_cus;
+                if (r_eff >= 1024.) mode = MCSAS_EXEC_WAVE;
+                else if (r_eff <= 192. && pipe_ok) mode = MCSAS_EXEC_PIPELINE;
+                else if (wg_ok) mode = MCSAS_EXEC_WORKGROUP;
+                else mode = MCSAS_EXEC_WAVE;
+            }
         }
     }
     if (wide_q) {
@@ -676,13 +707,7 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     hot.q = pa.c.q; hot.w = pa.c.w; hot.wI = pa.c.wI; hot.chains = pa.chains;
     hot.n_reps = pa.c.n_reps; hot.n_contrib = pa.c.n_contrib; hot.n_active = pa.c.model.n_active; hot.qpad = pa.c.qpad;
     hot.kb = pa.g.kb; hot.prod_blocks_y = pa.g.prod_blocks_y; hot.w_sub = pa.g.w; hot.max_iter = pa.c.max_iter;
-    hot.q3inv = pl->d_q3inv; hot.sub_per_block = pa.g.sub_per_block;
-    hot.rset = pa.c.rset; hot.cache = pa.c.cache; hot.row_valid = pa.row_valid; hot.cache_rows = pa.c.cache_rows;
-    hot.light_lazy = pa.g.lazy_rows; hot.light = (pa.g.gram_lds || pa.g.overlap) ? 1 : 0;
-    {   // row shares of a SIMD's two producer waves (chain_pipe.h): the LDS variant gives the older wave one row more
-        const int bits = (MCSAS_TUNE_BITS(pl->args) >> 19) & 3;
-        hot.skew = pa.g.gram_lds ? (bits == 0 ? 1 : (bits == 3 ? 0 : bits)) : bits;
-    }
+    hot.q3inv = pl->d_q3inv;
     long long t = -1;                                    // launch t = {SCAN(t), PROD(t+1)}
     for (; t < max_ticks; ++t) {
         if (t >= mcsas_plan::RING && (t % 16) == 0) {

@@ -965,11 +965,12 @@ def test_pipeline_geometry_follows_the_chain_count():
         plan = engine.Plan(m.setup(), q, I, sig, st)
         assert plan.info["exec_mode"] == "pipeline" and plan.info["window"] == 192, (reps, plan.info)
         plan.close()
-    # Kholodenko, 600 contributions: 13 chains -> 18 producer blocks per chain (247 blocks, one round): window 144;
-    # 50 chains -> 29 blocks per chain (1500 blocks, 5.9 rounds): window 232
+    # Kholodenko, 600 contributions, rows of varying cost: two rows per producer wave, dealt by predicted cost.  13 chains ->
+    # 16 producer blocks of 16 rows per chain (221 blocks, one round; the window is capped at 256 steps): window 256;
+    # 50 chains -> 14 blocks per chain (750 blocks, three rounds): window 224
     g = load("g9_kho_q512.npz")
     mk, _ = make_models("kholodenko", g["spec_lo"], g["spec_hi"])
-    for reps, window in ((13, 144), (50, 232)):
+    for reps, window in ((13, 256), (50, 224)):
         st = engine.Settings(n_contrib=600, n_reps=reps, max_iter=10, conv_crit=0.0, max_retries=0, seed=1, exec_mode=engine.EXEC_PIPELINE)
         plan = engine.Plan(mk.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st)
         assert plan.info["window"] == window, (reps, plan.info)
