@@ -16,7 +16,9 @@
 #ifndef MCSAS_HIP_H
 #define MCSAS_HIP_H
 
+#ifndef __HIPCC_RTC__   /* (the library's run-time compiler has the fixed-width types built in) */
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -38,7 +40,8 @@ enum {
     MCSAS_MODEL_SPH_CS = 5,      /* models/sphericalcoreshell.py:14-77 (radius, t, eta_c, eta_s, eta_sol) */
     MCSAS_MODEL_GAUSS_CHAIN = 6, /* models/gaussianchain.py:14-66      (rg, bp, etas, k) */
     MCSAS_MODEL_LMA_SPHERE = 7,  /* models/lmadensesphere.py:14-106    (radius, volFrac, mf, sld) */
-    MCSAS_MODEL_COUNT = 8
+    MCSAS_MODEL_COUNT = 8,
+    MCSAS_MODEL_PLUGIN = 8       /* template slot of a run-time plug-in (mcsas_hip_plugin_compile); callers use the id that call returns */
 };
 
 /* gen_kind: NumberGenerator subclass of an active parameter (bases/algorithm/numbergenerator.py) */
@@ -49,7 +52,12 @@ enum {
     MCSAS_GEN_EXP3 = 3      /* RandomExponential3  :186-189 (10^(3u) - 1)/1000 */
 };
 
-/* exec_mode: how chains are mapped onto the chip (results are identical, only speed differs) */
+/* exec_mode: how chains are mapped onto the chip.  Every mode replays the reference's trajectories decision for decision
+ * (tests/test_parity_gpu.py); the modes sum the same terms in different orders, so two FREE-RUNNING chains with the same
+ * seed can take different turns at a numerically tied step (replacing one negligible contribution by another moves chi²
+ * by less than its rounding error).  A repetition's result is reproducible for the same mode — whatever the number of
+ * repetitions or devices beside it for rows without an integral (the pipeline's window does not depend on the chain count);
+ * for rows with an integral the pipeline's window does follow the chain count (csrc/chain_pipe.h: pipe_geometry). */
 enum {
     MCSAS_EXEC_AUTO = 0,
     MCSAS_EXEC_WAVE = 1,      /* one wavefront per chain: many repetitions (>= ~1000) */

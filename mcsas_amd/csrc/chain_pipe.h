@@ -45,7 +45,7 @@ namespace mcsas {
 // next step that comes behind this step's sixteen row stores drains them (a memory round trip per row).  The rows are
 // therefore waited for HERE, in front of the stores: everything outstanding at this point was issued before the row was
 // evaluated.  Routing the values through an empty asm pins the wait (and the stores behind it) to this place.
-#define PIPE_TL_WORDS 26                 /* timeline record of a wave: start, end, HW_ID, XCC_ID, then 22 marks */
+#define PIPE_TL_WORDS 30                 /* timeline record of a wave: start, end, HW_ID, XCC_ID, then 26 marks */
 #ifdef MCSAS_STAMPS
 #define PIPE_TL_WRITE(pa, t, i) do { if ((pa).timeline && (t) - 1 == (pa).timeline_tick && (threadIdx.x & 63) == 0) (pa).timeline[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * PIPE_TL_WORDS + 4 + (i)] = wall_clock64(); } while (0)
 #else
@@ -53,6 +53,13 @@ namespace mcsas {
 #endif
 #define PIPE_TLX_MARK(pa, t, i) PIPE_TL_WRITE(pa, t, 18 + (i))   /* start-up marks 18..21: tables in LDS, proposals prepared, stale rows refreshed, row loop */
 #define PIPE_TL_MARK(pa, t, i) PIPE_TL_WRITE(pa, t, i)
+#ifdef MCSAS_STAMPS                      /* entry marks 22..25: clocks taken into registers (no argument-block read in the way), written later */
+#define PIPE_TL_CLOCK(var) const uint64_t var = wall_clock64()
+#define PIPE_TL_PUT(pa, t, i, var) do { if ((pa).timeline && (t) - 1 == (pa).timeline_tick && (threadIdx.x & 63) == 0) (pa).timeline[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * PIPE_TL_WORDS + 4 + (i)] = (var); } while (0)
+#else
+#define PIPE_TL_CLOCK(var) do {} while (0)
+#define PIPE_TL_PUT(pa, t, i, var) do {} while (0)
+#endif
 #define PIPE_PIN_ROW(arr) do { _Pragma("unroll") for (int j_ = 0; j_ < QPL; ++j_) asm volatile("" : "+v"(arr[j_])); } while (0)
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -743,8 +750,10 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         const int i = tid + PIPE_BLOCK * x < qpad ? tid + PIPE_BLOCK * x : 0;
         tq[x] = glb(hot.q)[i]; tw[x] = glb(hot.w)[i]; twI[x] = glb(hot.wI)[i]; tq3[x] = glb(hot.q3inv)[i];
     }
+    PIPE_TL_CLOCK(c_entry);                                   // (hot arguments in registers, loads issued)
     const PipeSnap sn = load_snap(&hot.chains[rep].snap[t & 1]);
     if (!sn.alive || t < sn.t_init) return;
+    PIPE_TL_CLOCK(c_snap);
 
     double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
 #pragma unroll
@@ -752,9 +761,12 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         const int i = tid + PIPE_BLOCK * x;
         if (i < qpad) { lq[i] = tq[x]; lw[i] = tw[x]; lwI[i] = twI[x]; lq3[i] = tq3[x]; }
     }
+    PIPE_TL_CLOCK(c_tab);
     Contrib<M>::fill_table(a.model, tab, tid, PIPE_BLOCK);
     if (tid == 0) *reinterpret_cast<int32_t *>(lds + pa.g.gram_off + 16) = 0;   // lazy rows: the block's stale-row count
     __syncthreads();
+    PIPE_TL_CLOCK(c_bar);
+    PIPE_TL_PUT(pa, t, 22, c_entry); PIPE_TL_PUT(pa, t, 23, c_snap); PIPE_TL_PUT(pa, t, 24, c_tab); PIPE_TL_PUT(pa, t, 25, c_bar);
     const QTables qt = make_qtables<M>(a.model, lq, lq3, tab);
     auto rset = glb(a.rset) + (size_t)rep * N * P;
     auto cache = glb(a.cache) + (size_t)rep * a.cache_rows * qpad;

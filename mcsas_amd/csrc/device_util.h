@@ -1,7 +1,9 @@
 // device_util.h — wave64 primitives for the McSAS chain kernels (gfx950 / CDNA4 only).
 #pragma once
+#ifndef __HIPCC_RTC__          /* hiprtc (run-time model plug-ins) brings the device runtime and the fixed-width types itself */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace mcsas {
 

@@ -11,7 +11,9 @@
 //   j1_fast / j1_core  <= 5e-16 absolute against scipy's Cephes j1;  div_fast <= 1 ulp;  rsqrt_fast <= 1.5 ulp.
 // Larger arguments take the libm path.
 #pragma once
+#ifndef __HIPCC_RTC__
 #include <math.h>
+#endif
 
 #if defined(__HIPCC__)
 #define MCSAS_HD __host__ __device__ __forceinline__

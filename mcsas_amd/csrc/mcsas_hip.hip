@@ -14,6 +14,7 @@
 
 #include "../../include/mcsas_hip.h"
 #include "chain_common.h"
+#include "small_kernels.h"   // model_rows_kernel, observability_kernel, hist_rows_kernel
 #include "chain_wg.h"   // WgGeom / wg_geometry only; the kernels are instantiated in kern_*.hip
 #include "chain_pipe.h" // PipeArgs / pipe_geometry only
 #include "auto_table.h" // measured rates of the execution modes (tools/make_auto_table.py)
@@ -37,27 +38,6 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 // ------------------------------------------------------------------------------ small kernels
-// rows[n][q] = SASModel.calcIntensity()[0] for contribution n (sasmodel.py:46-79); one wave per row
-template <int M>
-__global__ __launch_bounds__(64) void model_rows_kernel(ModelArgs m, int nq, const double *q, const double *pset,
-                                                        int n, double *rows, double *vset, double *wset, double *sset) {
-    extern __shared__ double tab[];
-    Contrib<M>::fill_table(m, tab, threadIdx.x, WAVE);
-    __syncthreads();
-    const int i = blockIdx.x;
-    double row[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
-    for (int p = 0; p < m.n_active; ++p) row[p] = pset[(size_t)i * m.n_active + p];
-    Contrib<M> c;
-    c.prepare(m, row);
-    if (threadIdx.x == 0) { vset[i] = c.v; wset[i] = c.w; sset[i] = c.s; }
-    for (int k = threadIdx.x; k < nq; k += WAVE) {
-        double it;
-        if (model_can_smear(M) && m.smear_nk > 0) it = smeared_intensity<M>(c, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
-        else it = c.intensity(q[k], tab);
-        rows[(size_t)i * nq + k] = it;
-    }
-}
-
 // cumInt += it, contribution by contribution (scatteringmodel.py:101): thread per q, fixed order
 __global__ void rows_cumsum_kernel(int nq, int n, const double *rows, double *cum) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,56 +75,7 @@ __global__ __launch_bounds__(64) void bgfit_kernel(int nq, const double *I, cons
     }
 }
 
-// min over q of sigma*vf / (A*I_c(q)), I_c != 0 (mcsas.py:582-590); one wave per (contribution, rep)
-template <int M>
-__global__ __launch_bounds__(64) void observability_kernel(ModelArgs m, int nq, const double *q, const double *sigma,
-                                                           int N, int R, const double *contribs, const double *scaling,
-                                                           const double *vol_frac, double *min_req) {
-    extern __shared__ double tab[];
-    Contrib<M>::fill_table(m, tab, threadIdx.x, WAVE);
-    __syncthreads();
-    const int c = blockIdx.x, r = blockIdx.y, P = m.n_active;
-    double row[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
-    for (int p = 0; p < P; ++p) row[p] = contribs[((size_t)c * P + p) * R + r];
-    Contrib<M> cc;
-    cc.prepare(m, row);
-    const double vf = vol_frac[(size_t)c * R + r], A = scaling[r];
-    double best = INFINITY;
-    for (int k = threadIdx.x; k < nq; k += WAVE) {
-        double it;
-        if (model_can_smear(M) && m.smear_nk > 0) it = smeared_intensity<M>(cc, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
-        else it = cc.intensity(q[k], tab);
-        double scaled = A * it;
-        if (scaled != 0.) best = fmin(best, (sigma[k] * vf) / scaled);
-    }
-    best = wave_min(best);
-    if (threadIdx.x == 0) min_req[(size_t)c * R + r] = best;
-}
-
 // ------------------------------------------------------------------------------ histogram(), batched
-// rows[r][c][q] = calcIntensity of contribution c of rep r, plus its v/w/s; one wave per (c, r)
-template <int M>
-__global__ __launch_bounds__(64) void hist_rows_kernel(ModelArgs m, int nq, const double *q, int N, int R, int r0,
-                                                       const double *contribs, double *rows, double *vset, double *wset,
-                                                       double *sset) {
-    extern __shared__ double tab[];
-    Contrib<M>::fill_table(m, tab, threadIdx.x, WAVE);
-    __syncthreads();
-    const int c = blockIdx.x, rl = blockIdx.y, r = r0 + rl, P = m.n_active;
-    double row[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
-    for (int p = 0; p < P; ++p) row[p] = contribs[((size_t)c * P + p) * R + r];
-    Contrib<M> cc;
-    cc.prepare(m, row);
-    if (threadIdx.x == 0) { vset[(size_t)c * R + r] = cc.v; wset[(size_t)c * R + r] = cc.w; sset[(size_t)c * R + r] = cc.s; }
-    double *out = rows + ((size_t)rl * N + c) * nq;
-    for (int k = threadIdx.x; k < nq; k += WAVE) {
-        double it;
-        if (model_can_smear(M) && m.smear_nk > 0) it = smeared_intensity<M>(cc, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
-        else it = cc.intensity(q[k], tab);
-        out[k] = it;
-    }
-}
-
 // per rep: cumInt = sum of its rows in contribution order (scatteringmodel.py:101), then the closed-form
 // scale/background fit (mcsas.py:559); one wave per rep
 __global__ __launch_bounds__(64) void hist_fit_kernel(int nq, const double *I, const double *sigma, int N, int R, int r0,
@@ -329,7 +260,41 @@ struct DeviceGuard {
 };
 
 // ------------------------------------------------------------------------------ plan
+// Device memory of a plan.  The big arrays (row cache, window buffers, replay streams: tens of MB) are allocations of their
+// own; everything else — the data vectors, the chains' records and running sums, parameter sets, the windows' scalars and
+// proposals, ~3 MB at config 2 — is carved out of 8 MB chunks, 256-byte aligned: a tick's blocks each touch a dozen of
+// these small arrays before their first row, and packed into one 2 MB-aligned range they share a handful of page-table
+// entries instead of one scattered 4 KB / 64 KB page per array (and a plan costs 6 hipMalloc calls instead of 25).
+struct DevPool {
+    static constexpr size_t CHUNK = (size_t)8 << 20, BIG = (size_t)2 << 20, ALIGN = 256;
+    std::vector<void *> blocks;         // everything to hipFree
+    char *cur = nullptr;
+    size_t left = 0;
+    hipError_t get(void **out, size_t n) {
+        *out = nullptr;
+        n = (n ? n : 1);
+        n = (n + ALIGN - 1) / ALIGN * ALIGN;
+        void *p = nullptr;
+        if (n >= BIG) {
+            hipError_t e = hipMalloc(&p, n);
+            if (e != hipSuccess) return e;
+            blocks.push_back(p); *out = p;
+            return hipSuccess;
+        }
+        if (n > left) {                 // (the tail of the old chunk stays unused)
+            hipError_t e = hipMalloc(&p, CHUNK);
+            if (e != hipSuccess) return e;
+            blocks.push_back(p); cur = (char *)p; left = CHUNK;
+        }
+        *out = cur; cur += n; left -= n;
+        return hipSuccess;
+    }
+    template <class T> hipError_t get(T **out, size_t n_bytes) { return get((void **)out, n_bytes); }
+    void release() { for (void *b : blocks) hipFree(b); blocks.clear(); cur = nullptr; left = 0; }
+};
+
 struct mcsas_plan {
+    DevPool pool;
     mcsas_problem prob;
     ChainArgs args;
     SmearDev smear;                     // device copy of the smearing tables (empty when off)
@@ -395,12 +360,9 @@ static void *wg_kernel_for(int model, int qpl) {
 
 extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     if (!pl) return;
-    hipFree(pl->d_q); hipFree(pl->d_w); hipFree(pl->d_wI); hipFree(pl->d_I); hipFree(pl->d_q3inv);
-    hipFree(pl->d_rset); hipFree(pl->d_cache); hipFree(pl->d_fit); hipFree(pl->d_replay); hipFree(pl->d_out);
+    pl->pool.release();                 // every device array of the plan
     if (pl->h_stop) hipHostFree(pl->h_stop);
     if (pl->h_done) hipHostFree(pl->h_done);
-    hipFree(pl->d_pipeargs); hipFree(pl->d_chains); hipFree(pl->d_ft); hipFree(pl->d_wft); hipFree(pl->d_dwin); hipFree(pl->d_gwin); hipFree(pl->d_scal); hipFree(pl->d_row_valid);
-    hipFree(pl->d_timeline); hipFree(pl->d_pval); hipFree(pl->d_slot_of); hipFree(pl->d_stage); hipFree(pl->d_povf);
     for (int i = 0; i < mcsas_plan::RING; ++i) {
         if (pl->evP[i]) hipEventDestroy(pl->evP[i]);
         if (pl->evS[i]) hipEventDestroy(pl->evS[i]);
@@ -554,7 +516,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         Sw += w; SI += w * p->intensity[i]; SII += w * p->intensity[i] * p->intensity[i]; Ss2 += e * e;
     }
     const size_t vb = sizeof(double) * qpad;
-    PCHK(hipMalloc(&pl->d_q, vb)); PCHK(hipMalloc(&pl->d_w, vb)); PCHK(hipMalloc(&pl->d_wI, vb)); PCHK(hipMalloc(&pl->d_I, vb));
+    PCHK(pl->pool.get(&pl->d_q, vb)); PCHK(pl->pool.get(&pl->d_w, vb)); PCHK(pl->pool.get(&pl->d_wI, vb)); PCHK(pl->pool.get(&pl->d_I, vb));
     PCHK(hipMemcpy(pl->d_q, hq.data(), vb, hipMemcpyHostToDevice));
     PCHK(hipMemcpy(pl->d_w, hw.data(), vb, hipMemcpyHostToDevice));
     PCHK(hipMemcpy(pl->d_wI, hwI.data(), vb, hipMemcpyHostToDevice));
@@ -563,14 +525,14 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         // rounded division the kernels used to make per block
         std::vector<double> hq3(qpad);
         for (int i = 0; i < qpad; ++i) hq3[i] = 1.0 / (hq[i] * hq[i] * hq[i]);
-        PCHK(hipMalloc(&pl->d_q3inv, vb));
+        PCHK(pl->pool.get(&pl->d_q3inv, vb));
         PCHK(hipMemcpy(pl->d_q3inv, hq3.data(), vb, hipMemcpyHostToDevice));
     }
 
     const size_t R = p->n_reps, N = p->n_contrib, P = p->n_active;
-    PCHK(hipMalloc(&pl->d_rset, sizeof(double) * R * N * P));
-    PCHK(hipMalloc(&pl->d_fit, sizeof(double) * R * qpad));
-    PCHK(hipMalloc(&pl->d_out, sizeof(ChainOut) * R));
+    PCHK(pl->pool.get(&pl->d_rset, sizeof(double) * R * N * P));
+    PCHK(pl->pool.get(&pl->d_fit, sizeof(double) * R * qpad));
+    PCHK(pl->pool.get(&pl->d_out, sizeof(ChainOut) * R));
     PCHK(hipMemset(pl->d_out, 0, sizeof(ChainOut) * R));
 
     // per-contribution intensity rows: the speculative kernels add two windows of spare row slots
@@ -592,11 +554,11 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         if ((mode != MCSAS_EXEC_WAVE || wide_q) && !use_cache) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_ENOMEM, "intensity cache (%zu MB) does not fit", cache_bytes >> 20); }
     }
     pl->use_cache = use_cache;
-    if (use_cache) PCHK(hipMalloc(&pl->d_cache, cache_bytes));
+    if (use_cache) PCHK(pl->pool.get(&pl->d_cache, cache_bytes));
 
     if (p->replay_stream) {
         size_t rb = sizeof(double) * R * (size_t)p->replay_len;
-        PCHK(hipMalloc(&pl->d_replay, rb));
+        PCHK(pl->pool.get(&pl->d_replay, rb));
         PCHK(hipMemcpy(pl->d_replay, p->replay_stream, rb, hipMemcpyHostToDevice));
     }
     PCHK(hipHostMalloc((void **)&pl->h_stop, sizeof(int32_t), hipHostMallocMapped));
@@ -632,17 +594,17 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     } else {
         PipeArgs &pa = pl->pipe;
         const size_t Kb = pa.g.kb;
-        PCHK(hipMalloc(&pl->d_chains, sizeof(PipeChain) * R));
-        PCHK(hipMalloc(&pl->d_pipeargs, sizeof(PipeArgs)));
-        PCHK(hipMalloc(&pl->d_ft, sizeof(double) * R * qpad)); PCHK(hipMalloc(&pl->d_wft, sizeof(double) * R * qpad));
-        PCHK(hipMalloc(&pl->d_slot_of, sizeof(int32_t) * R * N)); PCHK(hipMalloc(&pl->d_stage, sizeof(int32_t) * R * 2 * Kb));
-        PCHK(hipMalloc(&pl->d_dwin, sizeof(double) * R * 2 * Kb * qpad));
-        PCHK(hipMalloc(&pl->d_gwin, sizeof(double) * R * 2 * Kb * pa.g.w));
-        PCHK(hipMalloc(&pl->d_scal, sizeof(double) * R * 2 * Kb * 4));
-        PCHK(hipMalloc(&pl->d_row_valid, sizeof(int32_t) * R * N));
+        PCHK(pl->pool.get(&pl->d_chains, sizeof(PipeChain) * R));
+        PCHK(pl->pool.get(&pl->d_pipeargs, sizeof(PipeArgs)));
+        PCHK(pl->pool.get(&pl->d_ft, sizeof(double) * R * qpad)); PCHK(pl->pool.get(&pl->d_wft, sizeof(double) * R * qpad));
+        PCHK(pl->pool.get(&pl->d_slot_of, sizeof(int32_t) * R * N)); PCHK(pl->pool.get(&pl->d_stage, sizeof(int32_t) * R * 2 * Kb));
+        PCHK(pl->pool.get(&pl->d_dwin, sizeof(double) * R * 2 * Kb * qpad));
+        PCHK(pl->pool.get(&pl->d_gwin, sizeof(double) * R * 2 * Kb * pa.g.w));
+        PCHK(pl->pool.get(&pl->d_scal, sizeof(double) * R * 2 * Kb * 4));
+        PCHK(pl->pool.get(&pl->d_row_valid, sizeof(int32_t) * R * N));
         PCHK(hipMemset(pl->d_row_valid, 0, sizeof(int32_t) * R * N));
-        PCHK(hipMalloc(&pl->d_pval, sizeof(double) * R * 2 * Kb * MCSAS_MAX_ACTIVE));
-        PCHK(hipMalloc(&pl->d_povf, sizeof(int32_t) * R * 2 * Kb));
+        PCHK(pl->pool.get(&pl->d_pval, sizeof(double) * R * 2 * Kb * MCSAS_MAX_ACTIVE));
+        PCHK(pl->pool.get(&pl->d_povf, sizeof(int32_t) * R * 2 * Kb));
         PCHK(hipMemset(pl->d_povf, 0, sizeof(int32_t) * R * 2 * Kb));
         PCHK(hipHostMalloc((void **)&pl->h_done, sizeof(int32_t), hipHostMallocMapped));
         *pl->h_done = 0;
@@ -658,7 +620,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
 #ifdef MCSAS_STAMPS
         if (const char *e = getenv("MCSAS_TIMELINE_TICK")) {
             pa.timeline_tick = atoi(e);
-            PCHK(hipMalloc(&pl->d_timeline, sizeof(uint64_t) * 8 * PIPE_TL_WORDS * (R + R * pa.g.prod_blocks_y)));
+            PCHK(pl->pool.get(&pl->d_timeline, sizeof(uint64_t) * 8 * PIPE_TL_WORDS * (R + R * pa.g.prod_blocks_y)));
             PCHK(hipMemset(pl->d_timeline, 0, sizeof(uint64_t) * 8 * PIPE_TL_WORDS * (R + R * pa.g.prod_blocks_y)));
             pa.timeline = pl->d_timeline;
         }

@@ -5,7 +5,11 @@
 #pragma once
 #include "device_util.h"
 #include "fastmath.h"
+#ifdef __HIPCC_RTC__
+#include "mcsas_hip.h"               // (run-time compiler: the headers come from memory, by plain name)
+#else
 #include "../../include/mcsas_hip.h"
+#endif
 
 #ifndef MCSAS_ROW_GROUP
 #define MCSAS_ROW_GROUP 4       // sphere rows: q slots per lane evaluated in one interleaved group

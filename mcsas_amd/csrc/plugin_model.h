@@ -1,0 +1,50 @@
+// plugin_model.h — Contrib<MCSAS_MODEL_PLUGIN>: a scattering model whose form factor arrives as SOURCE TEXT at run time
+// (mcsas_hip_plugin_compile, include/mcsas_hip.h), the counterpart of the reference's model discovery: any models/*.py with a
+// ScatteringModel subclass is usable there (utils/findmodels.py:120-186) through four methods (bases/model/
+// scatteringmodel.py:15-58, sasmodel.py:36-79).  The plug-in text defines the same four, per q point and on the model's full
+// parameter vector p[MCSAS_MAX_PARAMS] (active parameters substituted and clipped into their valueRange like
+// Parameter.setValue does):
+//
+//     __device__ double mcsas_plugin_formfactor(double q, const double *p);   // ScatteringModel.formfactor(dataset) at one q
+//     __device__ double mcsas_plugin_volume(const double *p);                  // .volume()
+//     __device__ double mcsas_plugin_absvolume(const double *p);               // .absVolume()  (volume x contrast^2 where the model has one)
+//     __device__ double mcsas_plugin_surface(const double *p);                 // .surface()
+//
+// Everything in fastmath.h / device_util.h is available to it (sincos_fast, div_fast, j1_fast, ...).  This header is compiled
+// only by hiprtc, in a translation unit assembled by the library: chain_wave.h, small_kernels.h, this file, the plug-in text.
+#pragma once
+#include "models.h"
+
+__device__ double mcsas_plugin_formfactor(double q, const double *p);
+__device__ double mcsas_plugin_volume(const double *p);
+__device__ double mcsas_plugin_absvolume(const double *p);
+__device__ double mcsas_plugin_surface(const double *p);
+
+namespace mcsas {
+
+template <> struct Contrib<MCSAS_MODEL_PLUGIN> {
+    static constexpr int ROWTAB = 0;
+    double p[MCSAS_MAX_PARAMS];
+    double v, w, s;
+    static __device__ __forceinline__ int table_doubles(int) { return 0; }
+    static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
+    __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
+        full_params(a, row, p);
+        v = mcsas_plugin_absvolume(p);                             // vset: _volume() forwards to absVolume() (scatteringmodel.py:27-31)
+        s = mcsas_plugin_surface(p);
+        w = pow(mcsas_plugin_volume(p), 2. * a.comp_exp);          // weight() = volume()^(2c) (sasmodel.py:36-44)
+    }
+    __device__ __forceinline__ Contrib bcast(int lane) const {
+        Contrib o;
+#pragma unroll
+        for (int i = 0; i < MCSAS_MAX_PARAMS; ++i) o.p[i] = readlane_f64(p[i], lane);
+        o.w = readlane_f64(w, lane); o.v = 0.; o.s = 0.;
+        return o;
+    }
+    __device__ __forceinline__ double intensity(double q, const double *) const {
+        const double f = mcsas_plugin_formfactor(q, p);
+        return f * f * w;                                          // sasmodel.py:77
+    }
+};
+
+}  // namespace mcsas
