@@ -41,8 +41,10 @@ enum {
     MCSAS_MODEL_GAUSS_CHAIN = 6, /* models/gaussianchain.py:14-66      (rg, bp, etas, k) */
     MCSAS_MODEL_LMA_SPHERE = 7,  /* models/lmadensesphere.py:14-106    (radius, volFrac, mf, sld) */
     MCSAS_MODEL_COUNT = 8,
-    MCSAS_MODEL_PLUGIN = 8       /* template slot of a run-time plug-in (mcsas_hip_plugin_compile); callers use the id that call returns */
+    MCSAS_MODEL_PLUGIN = 8,      /* the template slot run-time plug-ins are compiled into (csrc/plugin_model.h); never a caller's model_id */
+    MCSAS_MODEL_PLUGIN0 = 64     /* first id mcsas_hip_plugin_compile hands out */
 };
+#define MCSAS_MAX_PLUGINS 32 /* plug-in models a process may register */
 
 /* gen_kind: NumberGenerator subclass of an active parameter (bases/algorithm/numbergenerator.py) */
 enum {
@@ -244,6 +246,22 @@ int mcsas_hip_prepare_uncertainty(int32_t n, const double *intensity, const doub
 int mcsas_hip_rebin(int32_t n, const double *x, const double *f, const double *fu, int32_t n_bin,
                     const double *edges, int32_t device, double *x_out, double *f_out, double *fu_out,
                     int32_t *n_out);
+
+/* Run-time model plug-in — what the reference's model discovery does for any file under models/ with a ScatteringModel subclass
+ * (utils/findmodels.py:120-186; the four methods a model supplies: bases/model/scatteringmodel.py:15-58, sasmodel.py:36-79).
+ * `source` is HIP C++ text that defines, per q point and on the model's full parameter vector p[MCSAS_MAX_PARAMS] (active
+ * parameters substituted and clipped into their valueRange):
+ *     __device__ double mcsas_plugin_formfactor(double q, const double *p);   // ScatteringModel.formfactor
+ *     __device__ double mcsas_plugin_volume(const double *p);                  // .volume()
+ *     __device__ double mcsas_plugin_absvolume(const double *p);               // .absVolume()
+ *     __device__ double mcsas_plugin_surface(const double *p);                 // .surface()
+ * (csrc/fastmath.h and device_util.h are in scope, namespace mcsas.)  The text is compiled with hiprtc for gfx950 against
+ * the library's own kernel headers, which it carries inside; no GPU is needed for that.  *model_id (>= MCSAS_MODEL_PLUGIN0)
+ * is then valid as mcsas_problem.model_id in every entry point; chains of a plug-in model run one wavefront per chain
+ * (exec_mode MCSAS_EXEC_AUTO or MCSAS_EXEC_WAVE, nq <= 1024; no beam-profile smearing).  The same text registered twice
+ * gives the same id.  MCSAS_EINVAL + mcsas_hip_plugin_log() (compiler output, calling thread) if it does not compile. */
+int         mcsas_hip_plugin_compile(const char *source, int32_t *model_id);
+const char *mcsas_hip_plugin_log(void);
 
 int         mcsas_hip_device_count(void);
 int         mcsas_hip_abi_version(void);

@@ -275,9 +275,8 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
 // rows (4 KB per step) — a contribution's cached row goes stale when its proposal is accepted and is evaluated again,
 // one q per thread, by the producer block that needs it as `old` N steps later (PipeGeom::lazy_rows).
 // Same function, same inputs as RowEval -> the same bits.
-constexpr bool pipe_light_model(int m) {
-    return m == MCSAS_MODEL_SPHERE || m == MCSAS_MODEL_SPH_CS || m == MCSAS_MODEL_GAUSS_CHAIN || m == MCSAS_MODEL_LMA_SPHERE;
-}
+// (Contrib<M>::ROW_CLASS == 0: sphere, core-shell sphere, Gaussian chain, LMA dense spheres)
+template <int M> constexpr bool pipe_light_model_v = Contrib<M>::ROW_CLASS == 0;
 template <int M>
 __device__ __forceinline__ double pipe_point_intensity(const Contrib<M> &c, double q, double q3inv, const double *tab) {
     if constexpr (M == MCSAS_MODEL_SPHERE) return c.fast ? c.intensity_fast(q, q3inv) : c.intensity(q, tab);
@@ -818,7 +817,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     }
 
     if (MCSAS_TUNE_BITS(a) & 16) return;                                  // diagnostic: no window rows
-    if constexpr (pipe_light_model(M)) if (pa.g.overlap || pa.g.gram_lds) {   // (rows with an integral never take this path: not instantiated for them)
+    if constexpr (pipe_light_model_v<M>) if (pa.g.overlap || pa.g.gram_lds) {   // (rows with an integral never take this path: not instantiated for them)
         // ---- overlapped producer.  The block's rows are nsb sub-windows of W; phase ss = the rows of sub-window ss, every
         // wave its share, d = new - old straight to the window buffer.  The Gram block of sub-window ss - 1 is worked off
         // in units BETWEEN the rows of phase ss (matrix pipe beside the vector pipe: while one wave of a SIMD is inside a run

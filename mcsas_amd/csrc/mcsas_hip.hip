@@ -1,6 +1,7 @@
 // mcsas_hip.hip — libmcsas_hip.so: C ABI (include/mcsas_hip.h) over the gfx950 chain kernels.
 // Built only for MI355X (gfx950); there is no CPU path in here.
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 
 #include <algorithm>
 #include <chrono>
@@ -8,6 +9,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -18,6 +22,7 @@
 #include "chain_wg.h"   // WgGeom / wg_geometry only; the kernels are instantiated in kern_*.hip
 #include "chain_pipe.h" // PipeArgs / pipe_geometry only
 #include "auto_table.h" // measured rates of the execution modes (tools/make_auto_table.py)
+#include "model_list.h" // MCSAS_FOR_MODELS: the built-in models
 
 using namespace mcsas;
 
@@ -158,29 +163,166 @@ __global__ __launch_bounds__(64) void rebin_kernel(int n, const double *x, const
     if (lane == 0) cnt_out[b] = c;
 }
 
-// ------------------------------------------------------------------------------ host helpers
-static int model_int_div(const mcsas_problem *p) {
-    switch (p->model_id) {
-        case MCSAS_MODEL_CYL_ISO: return (int)p->params[4];
-        case MCSAS_MODEL_ELL_CS: return (int)p->params[6];
-        case MCSAS_MODEL_ELL_ISO: return (int)p->params[4];
-        default: return 1;
+// ------------------------------------------------------------------------------ run-time model plug-ins (hiprtc)
+// The reference takes any models/*.py that subclasses ScatteringModel (utils/findmodels.py:120-186); here a model outside
+// the eight built-in ones arrives as HIP source text defining the four functions of plugin_model.h.  It is compiled for gfx950
+// against the library's OWN kernel headers (embedded at build time: embedded_headers.inc) — the wave-per-chain kernel and the
+// three model-templated small kernels, instantiated for Contrib<MCSAS_MODEL_PLUGIN> — and loaded as a code-object module on
+// every device that uses it.  Compilation needs no GPU; loading does.
+#include "embedded_headers.inc"
+
+struct Plugin {
+    std::string source;
+    std::mutex mu;
+    struct Program { std::vector<char> code; std::map<std::string, std::string> lowered; };
+    std::map<std::string, Program> programs;                                  // by program key ("small", "wave 8 1", ...)
+    std::map<std::pair<int, std::string>, hipModule_t> modules;               // (device, program key)
+};
+static std::mutex g_plugins_mu;
+static std::vector<std::unique_ptr<Plugin>> g_plugins;
+static thread_local std::string g_plugin_log;
+
+static bool is_plugin_model(int model_id) { return model_id >= MCSAS_MODEL_PLUGIN0 && model_id < MCSAS_MODEL_PLUGIN0 + MCSAS_MAX_PLUGINS; }
+static Plugin *plugin_of(int model_id) {
+    std::lock_guard<std::mutex> lk(g_plugins_mu);
+    const int k = model_id - MCSAS_MODEL_PLUGIN0;
+    return (k >= 0 && k < (int)g_plugins.size()) ? g_plugins[k].get() : nullptr;
+}
+
+// one translation unit: the kernel headers, the plug-in's Contrib, the plug-in text; `exprs` = the kernels to instantiate
+static int plugin_compile_program(const std::string &source, const std::vector<std::string> &exprs, Plugin::Program *out) {
+    // hiprtc has the fixed-width integer types in a namespace of its own
+    std::string tu =
+        "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
+        "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"
+        "#include \"chain_wave.h\"\n#include \"small_kernels.h\"\n#include \"plugin_model.h\"\n#line 1 \"plugin\"\n";
+    tu += source;
+    tu += "\n";
+    hiprtcProgram prog = nullptr;
+    hiprtcResult r = hiprtcCreateProgram(&prog, tu.c_str(), "mcsas_plugin.hip", mcsas_embedded_count, const_cast<const char **>(mcsas_embedded_texts),
+                                         const_cast<const char **>(mcsas_embedded_names));
+    if (r != HIPRTC_SUCCESS) return fail(MCSAS_EHIP, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+    for (const std::string &e : exprs) hiprtcAddNameExpression(prog, e.c_str());
+    // the flags of the Makefile: one contribution row must come out the same from every call site (-ffp-contract=off)
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"};
+    r = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
+    size_t ls = 0;
+    g_plugin_log.clear();
+    if (hiprtcGetProgramLogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) { g_plugin_log.resize(ls); hiprtcGetProgramLog(prog, &g_plugin_log[0]); }
+    if (r != HIPRTC_SUCCESS) {
+        hiprtcDestroyProgram(&prog);
+        return fail(MCSAS_EINVAL, "model plug-in does not compile (%s): see mcsas_hip_plugin_log()", hiprtcGetErrorString(r));
     }
+    size_t cs = 0;
+    hiprtcGetCodeSize(prog, &cs);
+    out->code.resize(cs);
+    hiprtcGetCode(prog, out->code.data());
+    for (const std::string &e : exprs) {
+        const char *ln = nullptr;
+        if (hiprtcGetLoweredName(prog, e.c_str(), &ln) != HIPRTC_SUCCESS || !ln) { hiprtcDestroyProgram(&prog); return fail(MCSAS_EHIP, "no lowered name for %s", e.c_str()); }
+        out->lowered[e] = ln;
+    }
+    hiprtcDestroyProgram(&prog);
+    return MCSAS_OK;
+}
+
+static const char *const PLUGIN_SMALL_EXPRS[3] = {"mcsas::model_rows_kernel<MCSAS_MODEL_PLUGIN>", "mcsas::observability_kernel<MCSAS_MODEL_PLUGIN>",
+                                                  "mcsas::hist_rows_kernel<MCSAS_MODEL_PLUGIN>"};
+
+// kernel `expr` of program `key` (compiled on first use) as a function of the CURRENT device's module
+static int plugin_function(int model_id, const std::string &key, const std::vector<std::string> &exprs, const std::string &expr, hipFunction_t *fn) {
+    Plugin *pg = plugin_of(model_id);
+    if (!pg) return fail(MCSAS_EINVAL, "model_id %d: no such plug-in (mcsas_hip_plugin_compile returns the id)", model_id);
+    std::lock_guard<std::mutex> lk(pg->mu);
+    auto it = pg->programs.find(key);
+    if (it == pg->programs.end()) {
+        Plugin::Program prg;
+        int rc = plugin_compile_program(pg->source, exprs, &prg);
+        if (rc) return rc;
+        it = pg->programs.emplace(key, std::move(prg)).first;
+    }
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    auto mk = std::make_pair(dev, key);
+    auto mi = pg->modules.find(mk);
+    if (mi == pg->modules.end()) {
+        hipModule_t mod = nullptr;
+        HIPCHK(hipModuleLoadData(&mod, it->second.code.data()));
+        mi = pg->modules.emplace(mk, mod).first;
+    }
+    HIPCHK(hipModuleGetFunction(fn, mi->second, it->second.lowered.at(expr).c_str()));
+    return MCSAS_OK;
+}
+static int plugin_small_function(int model_id, int which, hipFunction_t *fn) {
+    const std::vector<std::string> exprs(PLUGIN_SMALL_EXPRS, PLUGIN_SMALL_EXPRS + 3);
+    return plugin_function(model_id, "small", exprs, exprs[which], fn);
+}
+static int plugin_wave_function(int model_id, int qpl, bool cache, hipFunction_t *fn) {
+    char e[128], k[32];
+    snprintf(e, sizeof e, "mcsas::chain_wave_kernel<MCSAS_MODEL_PLUGIN, %d, %s>", qpl, cache ? "true" : "false");
+    snprintf(k, sizeof k, "wave %d %d", qpl, cache ? 1 : 0);
+    return plugin_function(model_id, k, {e}, e, fn);
+}
+
+// launch of small kernel `which` (PLUGIN_SMALL_EXPRS) of a plug-in on the null stream; the arguments are passed by address,
+// so their types must be the kernel's parameter types exactly
+template <class... A>
+static int plugin_small_launch(int model_id, int which, dim3 grid, size_t lds, A... args) {
+    hipFunction_t fn = nullptr;
+    int rc = plugin_small_function(model_id, which, &fn);
+    if (rc) return rc;
+    void *ka[] = {(void *)&args...};
+    HIPCHK(hipModuleLaunchKernel(fn, grid.x, grid.y, grid.z, WAVE, 1, 1, (unsigned)lds, nullptr, ka, nullptr));
+    return MCSAS_OK;
+}
+
+extern "C" int mcsas_hip_plugin_compile(const char *source, int32_t *model_id) {
+    if (!source || !model_id) return fail(MCSAS_EINVAL, "null argument");
+    *model_id = -1;
+    {
+        std::lock_guard<std::mutex> lk(g_plugins_mu);
+        for (size_t k = 0; k < g_plugins.size(); ++k)
+            if (g_plugins[k]->source == source) { *model_id = MCSAS_MODEL_PLUGIN0 + (int)k; return MCSAS_OK; }   // the same text again
+    }
+    // the small kernels are compiled here, so that a plug-in that does not compile is refused before anything uses it
+    auto pg = std::make_unique<Plugin>();
+    pg->source = source;
+    Plugin::Program prg;
+    const std::vector<std::string> exprs(PLUGIN_SMALL_EXPRS, PLUGIN_SMALL_EXPRS + 3);
+    int rc = plugin_compile_program(pg->source, exprs, &prg);
+    if (rc) return rc;
+    pg->programs.emplace("small", std::move(prg));
+    std::lock_guard<std::mutex> lk(g_plugins_mu);
+    if ((int)g_plugins.size() >= MCSAS_MAX_PLUGINS) return fail(MCSAS_EINVAL, "more than %d model plug-ins", MCSAS_MAX_PLUGINS);
+    g_plugins.push_back(std::move(pg));
+    *model_id = MCSAS_MODEL_PLUGIN0 + (int)g_plugins.size() - 1;
+    return MCSAS_OK;
+}
+extern "C" const char *mcsas_hip_plugin_log(void) { return g_plugin_log.c_str(); }
+
+// ------------------------------------------------------------------------------ host helpers
+// what the host needs to know about a model, read off its Contrib<M> (models.h) — no per-model code below this table
+struct ModelTraits { int int_div_param, rowtab, row_class; bool can_smear; int (*table_doubles)(int); };
+static const ModelTraits &model_traits(int model_id) {
+#define TRAITS_OF(m) {Contrib<m>::INT_DIV_PARAM, Contrib<m>::ROWTAB, Contrib<m>::ROW_CLASS, Contrib<m>::CAN_SMEAR, &Contrib<m>::table_doubles},
+    static const ModelTraits builtin[] = {MCSAS_FOR_MODELS(TRAITS_OF)};
+#undef TRAITS_OF
+    static const ModelTraits plugin = {-1, 0, 0, false, [](int) { return 0; }};      // plugin_model.h
+    static_assert(sizeof builtin / sizeof builtin[0] == MCSAS_MODEL_COUNT, "model_list.h and include/mcsas_hip.h disagree");
+    return (model_id >= 0 && model_id < MCSAS_MODEL_COUNT) ? builtin[model_id] : plugin;
+}
+static int model_int_div(const mcsas_problem *p) {
+    const int i = model_traits(p->model_id).int_div_param;
+    return i < 0 ? 1 : (int)p->params[i];
 }
 
 // per-wave scratch for the per-row orientation table (Contrib<M>::ROWTAB * K doubles, models.h); beyond
 // K = 256 the chain kernels evaluate the integrand directly
-static int rowtab_doubles_host(int model_id, int K) {
-    if (K > 256) return 0;
-    switch (model_id) {
-        case MCSAS_MODEL_CYL_ISO: case MCSAS_MODEL_ELL_CS: return 4 * K;
-        case MCSAS_MODEL_ELL_ISO: return 2 * K;
-        default: return 0;
-    }
-}
+static int rowtab_doubles_host(int model_id, int K) { return K > 256 ? 0 : model_traits(model_id).rowtab * K; }
 
 static int fill_model_args(const mcsas_problem *p, ModelArgs *m) {
-    if (p->model_id < 0 || p->model_id >= MCSAS_MODEL_COUNT) return fail(MCSAS_EINVAL, "unknown model_id %d", p->model_id);
+    if ((p->model_id < 0 || p->model_id >= MCSAS_MODEL_COUNT) && !(is_plugin_model(p->model_id) && plugin_of(p->model_id)))
+        return fail(MCSAS_EINVAL, "unknown model_id %d", p->model_id);
     if (p->n_active < 0 || p->n_active > MCSAS_MAX_ACTIVE) return fail(MCSAS_EINVAL, "n_active %d out of range", p->n_active);
     memset(m, 0, sizeof *m);
     m->model_id = p->model_id; m->n_active = p->n_active; m->comp_exp = p->comp_exp;
@@ -195,20 +337,12 @@ static int fill_model_args(const mcsas_problem *p, ModelArgs *m) {
     m->use_rowtab = rowtab_doubles_host(p->model_id, m->int_div) > 0;
     m->qmax = 0.;
     if (p->q) for (int i = 0; i < p->nq; ++i) m->qmax = std::max(m->qmax, std::fabs(p->q[i]));
-    if ((p->model_id == MCSAS_MODEL_CYL_ISO || p->model_id == MCSAS_MODEL_ELL_CS || p->model_id == MCSAS_MODEL_ELL_ISO) &&
-        (m->int_div < 2 || m->int_div > 4096))
+    if (model_traits(p->model_id).int_div_param >= 0 && (m->int_div < 2 || m->int_div > 4096))
         return fail(MCSAS_EINVAL, "intDiv %d unsupported (2..4096)", m->int_div);
     return MCSAS_OK;
 }
 
-static int table_doubles_host(int model_id, int K) {
-    switch (model_id) {
-        case MCSAS_MODEL_CYL_ISO: case MCSAS_MODEL_ELL_CS: return 2 * K;
-        case MCSAS_MODEL_ELL_ISO: return 3 * K;
-        case MCSAS_MODEL_KHOLODENKO: return 32;
-        default: return 0;
-    }
-}
+static int table_doubles_host(int model_id, int K) { return model_traits(model_id).table_doubles(K); }
 // Device copy of the smearing tables of a problem: locs transposed to [K][stride] (pad columns repeat
 // column 0, like the padded q) and cw[m] = 2 * trapezoid coefficient(q_offset)[m] * weights[m], so that
 // sum_m cw[m] y[m] = 2 trapz(y * weights, x = q_offset) (sasmodel.py:72-73).
@@ -218,7 +352,7 @@ struct SmearDev {
     int upload(const mcsas_problem *p, int stride, ModelArgs *m) {
         m->smear_nk = 0; m->smear_stride = 0; m->smear_locs_t = nullptr; m->smear_cw = nullptr;
         if (p->smear_nk <= 0) return MCSAS_OK;
-        if (!(p->model_id == MCSAS_MODEL_SPHERE || p->model_id == MCSAS_MODEL_LMA_SPHERE)) return MCSAS_OK;   // canSmear = False
+        if (!model_traits(p->model_id).can_smear) return MCSAS_OK;   // canSmear = False
         const int K = p->smear_nk;
         if (K < 2 || K > 4096 || !p->smear_locs || !p->smear_q_offset || !p->smear_weights)
             return fail(MCSAS_EINVAL, "smearing: smear_nk %d (2..4096) needs locs, q_offset and weights", K);
@@ -319,6 +453,7 @@ struct mcsas_plan {
     uint64_t *d_timeline = nullptr;
     int32_t *h_done = nullptr;          // pinned + mapped: scan kernels count finished chains into it
     PipeArgs *d_pipeargs = nullptr;     // the argument block the tick kernels read (device copy)
+    hipFunction_t plugin_fn = nullptr;  // wave kernel of a run-time model plug-in (this device's module), else null
     hipStream_t sP = nullptr, sS = nullptr;
     static constexpr int RING = 64;
     hipEvent_t evP[RING] = {}, evS[RING] = {};
@@ -326,7 +461,6 @@ struct mcsas_plan {
 };
 
 // kernel lookups, one translation unit per model (kern_wave.hip / kern_wg.hip)
-#define MCSAS_FOR_MODELS(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define DECL_K(m) void *mcsas_wave_kernel_m##m(int, bool); void *mcsas_wg_kernel_m##m(int); void *mcsas_pipe_tick_kernel_m##m(int);
 MCSAS_FOR_MODELS(DECL_K)
 #undef DECL_K
@@ -448,8 +582,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
     const int tab_shared = table_doubles_host(p->model_id, margs.int_div), tab_row = rowtab_doubles_host(p->model_id, margs.int_div);
     // rows that cost a numerical integration each (2: and whose cost varies with the parameter set — chain_pipe.h, pipe_geometry)
-    const int heavy_rows = (p->model_id == MCSAS_MODEL_KHOLODENKO || p->model_id == MCSAS_MODEL_CYL_ISO) ? 2
-                           : ((tab_shared > 0 || margs.smear_nk > 0) ? 1 : 0);
+    const int heavy_rows = std::max(model_traits(p->model_id).row_class, margs.smear_nk > 0 ? 1 : 0);
     int n_cus = 256;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, pl->dev) == hipSuccess && v > 0) n_cus = v; }
 #ifdef MCSAS_TUNING
@@ -467,6 +600,15 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     // execution mode (results do not depend on it)
     int mode = p->exec_mode;
     int waves = p->waves_per_chain;
+    const bool plugin = is_plugin_model(p->model_id);
+    if (plugin) {
+        // run-time model plug-ins are compiled into the wave-per-chain kernel only (plugin_model.h)
+        if ((mode != MCSAS_EXEC_AUTO && mode != MCSAS_EXEC_WAVE) || waves > 1 || wide_q) {
+            mcsas_hip_plan_destroy(pl);
+            return fail(MCSAS_EINVAL, "model plug-ins run one wavefront per chain, nq <= 1024 (exec_mode %d, waves_per_chain %d, nq %d asked)", p->exec_mode, waves, p->nq);
+        }
+        mode = MCSAS_EXEC_WAVE; waves = 1;
+    }
     if (mode == MCSAS_EXEC_AUTO) {
         if (waves == 1) mode = MCSAS_EXEC_WAVE;
         else if (waves > 1) mode = MCSAS_EXEC_WORKGROUP;
@@ -588,7 +730,10 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
 
     if (mode == MCSAS_EXEC_WAVE) {
         pl->lds_bytes = sizeof(double) * (4 * (size_t)qpad + TABD(1));
-        if (!wave_kernel_for(p->model_id, qpl, use_cache)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no kernel for model %d qpl %d", p->model_id, qpl); }
+        if (plugin) {
+            rc = plugin_wave_function(p->model_id, qpl, use_cache != 0, &pl->plugin_fn);     // (compiled on first use of this q count)
+            if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
+        } else if (!wave_kernel_for(p->model_id, qpl, use_cache)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no kernel for model %d qpl %d", p->model_id, qpl); }
     } else if (mode == MCSAS_EXEC_WORKGROUP) {
         pl->lds_bytes = pl->wg.lds_bytes;
     } else {
@@ -703,6 +848,13 @@ extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
     void *kargs[] = {(void *)&pl->args};
     void *fn;
     dim3 grid(pl->prob.n_reps), block;
+    if (pl->plugin_fn) {
+        HIPCHK(hipEventRecord(pl->ev0, st));
+        HIPCHK(hipModuleLaunchKernel(pl->plugin_fn, grid.x, 1, 1, WAVE, 1, 1, (unsigned)pl->lds_bytes, st, kargs, nullptr));
+        HIPCHK(hipEventRecord(pl->ev1, st));
+        pl->stream = st; pl->launched = true;
+        return MCSAS_OK;
+    }
     if (pl->mode == MCSAS_EXEC_WAVE) {
         fn = wave_kernel_for(pl->prob.model_id, pl->qpl, pl->use_cache);
         block = dim3(WAVE);
@@ -975,7 +1127,10 @@ extern "C" int mcsas_hip_model_calc(const mcsas_problem *p, const double *pset, 
 #define CASE_K(mm) case mm: model_rows_kernel<mm><<<n, WAVE, lds>>>(m, p->nq, dq.p, dp.p, n, dr.p, dv.p, dw.p, ds.p); break;
         MCSAS_FOR_MODELS(CASE_K)
 #undef CASE_K
-        default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
+        default:
+            if (!is_plugin_model(p->model_id)) return fail(MCSAS_EINVAL, "model %d", p->model_id);
+            rc = plugin_small_launch(p->model_id, 0, dim3(n), lds, m, (int)p->nq, (const double *)dq.p, (const double *)dp.p, (int)n, dr.p, dv.p, dw.p, ds.p);
+            if (rc) return rc;
     }
     HIPCHK(hipGetLastError());
     rows_cumsum_kernel<<<(p->nq + 255) / 256, 256>>>(p->nq, n, dr.p, dc.p);
@@ -1033,7 +1188,12 @@ extern "C" int mcsas_hip_observability(const mcsas_problem *p, const double *con
 #define CASE_K(mm) case mm: observability_kernel<mm><<<grid, WAVE, lds>>>(m, p->nq, dq.p, dsg.p, (int)N, (int)R, dc.p, dsc.p, dvf.p, dm.p); break;
         MCSAS_FOR_MODELS(CASE_K)
 #undef CASE_K
-        default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
+        default: {
+            if (!is_plugin_model(p->model_id)) return fail(MCSAS_EINVAL, "model %d", p->model_id);
+            int rcp = plugin_small_launch(p->model_id, 1, grid, lds, m, (int)p->nq, (const double *)dq.p, (const double *)dsg.p, (int)N, (int)R,
+                                          (const double *)dc.p, (const double *)dsc.p, (const double *)dvf.p, dm.p);
+            if (rcp) return rcp;
+        }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(min_req_vol, dm.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
@@ -1073,7 +1233,12 @@ extern "C" int mcsas_hip_histogram_prep(const mcsas_problem *p, const double *co
 #define CASE_K(mm) case mm: hist_rows_kernel<mm><<<grid, WAVE, lds>>>(m, p->nq, dq.p, (int)N, (int)R, (int)r0, dc.p, drows.p, dv.p, dw.p, ds.p); break;
             MCSAS_FOR_MODELS(CASE_K)
 #undef CASE_K
-            default: return fail(MCSAS_EINVAL, "model %d", p->model_id);
+            default: {
+                if (!is_plugin_model(p->model_id)) return fail(MCSAS_EINVAL, "model %d", p->model_id);
+                int rcp = plugin_small_launch(p->model_id, 2, grid, lds, m, (int)p->nq, (const double *)dq.p, (int)N, (int)R, (int)r0, (const double *)dc.p,
+                                              drows.p, dv.p, dw.p, ds.p);
+                if (rcp) return rcp;
+            }
         }
         HIPCHK(hipGetLastError());
         hist_fit_kernel<<<nr, WAVE>>>(p->nq, dI.p, dsg.p, (int)N, (int)R, (int)r0, drows.p, p->find_background != 0,

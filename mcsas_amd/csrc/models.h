@@ -45,8 +45,16 @@ struct QTables {
     int smear_nk, smear_stride;
 };
 
+// One specialisation per model: everything the library knows about a model is in it.
+//   ROWTAB         doubles per orientation point of the per-row table (0: the model has none)
+//   INT_DIV_PARAM  index of the quadrature point count in params[], -1 if the model has no orientation / contour integral
+//   ROW_CLASS      0: a row costs a few hundred instructions (no integral) — the pipeline keeps its `d` rows in LDS and
+//                  re-evaluates stale rows instead of storing new ones; 1: a row costs an integral; 2: ... whose cost also
+//                  varies with the parameter set (row_cost below deals such rows out by predicted cost)
+//   CAN_SMEAR      the reference's canSmear flag (sasmodel.py:56-60)
+//   table_doubles(K), fill_table()   shared orientation table in LDS;  prepare() / bcast() / intensity()   a contribution
+// Adding a built-in model: a specialisation here, its id in include/mcsas_hip.h and in model_list.h.
 template <int M> struct Contrib;
-constexpr bool model_can_smear(int m) { return m == MCSAS_MODEL_SPHERE || m == MCSAS_MODEL_LMA_SPHERE; }
 
 // smeared intensity at data point i: sum_m cw[m] * I(locs[i][m])  (I = F^2 w, so this is
 // 2 trapz(F^2 w weights, x = qOffset), sasmodel.py:72-73)
@@ -79,9 +87,11 @@ constexpr double PI = 3.141592653589793;
 // models/sphere.py:32-63
 template <> struct Contrib<MCSAS_MODEL_SPHERE> {
     static constexpr int ROWTAB = 0;
+    static constexpr int INT_DIV_PARAM = -1, ROW_CLASS = 0;   // index of intDiv in params[] (-1: none); cost class of a row (see the head of this file)
+    static constexpr bool CAN_SMEAR = true;
     double r, v, w, s, invr3;
     int fast;              // q*r < 2^20 for every q of the data set: branch-free sincos is valid
-    static __device__ __forceinline__ int table_doubles(int) { return 0; }
+    static __host__ __device__ __forceinline__ int table_doubles(int) { return 0; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
     __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
         double p[MCSAS_MAX_PARAMS];
@@ -132,9 +142,11 @@ template <> struct Contrib<MCSAS_MODEL_SPHERE> {
 // models/cylindersisotropic.py:50-101.  table: x_k (ends replaced by 0.5, :60-61) and sqrt(1-x_k^2)
 template <> struct Contrib<MCSAS_MODEL_CYL_ISO> {
     static constexpr int ROWTAB = 4;       // per orientation k: r sqrt(1-x^2), hl x, 1/(2 r sqrt(1-x^2) hl x), 1/(r sqrt(1-x^2))
+    static constexpr int INT_DIV_PARAM = 4, ROW_CLASS = 2;   // index of intDiv in params[] (-1: none); cost class of a row (see the head of this file)
+    static constexpr bool CAN_SMEAR = false;
     double r, hl, v, w, s, step;
     int K, fast;
-    static __device__ __forceinline__ int table_doubles(int K) { return 2 * K; }
+    static __host__ __device__ __forceinline__ int table_doubles(int K) { return 2 * K; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &a, double *tab, int tid, int nt) {
         int K = a.int_div;
         double step = 1.0 / (double)(K - 1);
@@ -268,9 +280,11 @@ template <> struct Contrib<MCSAS_MODEL_CYL_ISO> {
 // models/ellipsoidalcoreshell.py:59-97.  table: mu_k^2 and 1-mu_k^2
 template <> struct Contrib<MCSAS_MODEL_ELL_CS> {
     static constexpr int ROWTAB = 4;       // per orientation k: R_core, R_total, 3 c1 / R_core^3, 3 c2 / R_total^3
+    static constexpr int INT_DIV_PARAM = 6, ROW_CLASS = 1;   // index of intDiv in params[] (-1: none); cost class of a row (see the head of this file)
+    static constexpr bool CAN_SMEAR = false;
     double a2, b2, at2, bt2, c1, c2, v, w, s, invK;
     int K, fast;
-    static __device__ __forceinline__ int table_doubles(int K) { return 2 * K; }
+    static __host__ __device__ __forceinline__ int table_doubles(int K) { return 2 * K; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &a, double *tab, int tid, int nt) {
         int K = a.int_div;
         double step = 1.0 / (double)(K - 1);
@@ -370,8 +384,10 @@ template <> struct Contrib<MCSAS_MODEL_ELL_CS> {
 // table: GL-16 nodes then weights on [-1, 1].
 template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
     static constexpr int ROWTAB = 0;
+    static constexpr int INT_DIV_PARAM = -1, ROW_CLASS = 2;   // index of intDiv in params[] (-1: none); cost class of a row (see the head of this file)
+    static constexpr bool CAN_SMEAR = false;
     double r, lk, x, ratio, v, w, s;
-    static __device__ __forceinline__ int table_doubles(int) { return 32; }
+    static __host__ __device__ __forceinline__ int table_doubles(int) { return 32; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *tab, int tid, int) {
         const double nd[8] = {9.50125098376374544e-02, 2.81603550779258915e-01, 4.58016777657227370e-01,
                               6.17876244402643771e-01, 7.55404408355002999e-01, 8.65631202387831755e-01,
@@ -538,9 +554,11 @@ template <> struct Contrib<MCSAS_MODEL_KHOLODENKO> {
 // alpha = linspace(0, pi/2, K)
 template <> struct Contrib<MCSAS_MODEL_ELL_ISO> {
     static constexpr int ROWTAB = 2;       // per orientation k: R_k, 3 sqrt(sin alpha_k) / R_k^3
+    static constexpr int INT_DIV_PARAM = 4, ROW_CLASS = 1;   // index of intDiv in params[] (-1: none); cost class of a row (see the head of this file)
+    static constexpr bool CAN_SMEAR = false;
     double ra2, rc2, v, w, s, invK;
     int K, fast;
-    static __device__ __forceinline__ int table_doubles(int K) { return 3 * K; }
+    static __host__ __device__ __forceinline__ int table_doubles(int K) { return 3 * K; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &a, double *tab, int tid, int nt) {
         const int K = a.int_div;
         const double step = (PI / 2.) / (double)(K - 1);
@@ -614,8 +632,10 @@ template <> struct Contrib<MCSAS_MODEL_ELL_ISO> {
 // models/sphericalcoreshell.py:50-77
 template <> struct Contrib<MCSAS_MODEL_SPH_CS> {
     static constexpr int ROWTAB = 0;
+    static constexpr int INT_DIV_PARAM = -1, ROW_CLASS = 0;   // index of intDiv in params[] (-1: none); cost class of a row (see the head of this file)
+    static constexpr bool CAN_SMEAR = false;
     double r, rt, ds, dc, vr, v, w, s;
-    static __device__ __forceinline__ int table_doubles(int) { return 0; }
+    static __host__ __device__ __forceinline__ int table_doubles(int) { return 0; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
     __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
         double p[MCSAS_MAX_PARAMS];
@@ -651,8 +671,10 @@ template <> struct Contrib<MCSAS_MODEL_SPH_CS> {
 // models/gaussianchain.py:54-66
 template <> struct Contrib<MCSAS_MODEL_GAUSS_CHAIN> {
     static constexpr int ROWTAB = 0;
+    static constexpr int INT_DIV_PARAM = -1, ROW_CLASS = 0;   // index of intDiv in params[] (-1: none); cost class of a row (see the head of this file)
+    static constexpr bool CAN_SMEAR = false;
     double rg, beta, v, w, s;
-    static __device__ __forceinline__ int table_doubles(int) { return 0; }
+    static __host__ __device__ __forceinline__ int table_doubles(int) { return 0; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
     __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
         double p[MCSAS_MAX_PARAMS];
@@ -681,8 +703,10 @@ template <> struct Contrib<MCSAS_MODEL_GAUSS_CHAIN> {
 // models/lmadensesphere.py:58-106: sphere form factor times a Percus-Yevick structure factor
 template <> struct Contrib<MCSAS_MODEL_LMA_SPHERE> {
     static constexpr int ROWTAB = 0;
+    static constexpr int INT_DIV_PARAM = -1, ROW_CLASS = 0;   // index of intDiv in params[] (-1: none); cost class of a row (see the head of this file)
+    static constexpr bool CAN_SMEAR = true;
     double r, rh, mu, al, be, ga, v, w, s;
-    static __device__ __forceinline__ int table_doubles(int) { return 0; }
+    static __host__ __device__ __forceinline__ int table_doubles(int) { return 0; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
     __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
         double p[MCSAS_MAX_PARAMS];
@@ -771,7 +795,7 @@ __device__ __forceinline__ double row_cost(const Contrib<M> &c, const double *lq
 // sincos (and J1) and two FMAs per (q, k).
 template <int M, int QPL> struct RowEval {
     static __device__ __forceinline__ void run(const Contrib<M> &c, const QTables &t, int lane, double (&out)[QPL]) {
-        if constexpr (model_can_smear(M)) {
+        if constexpr (Contrib<M>::CAN_SMEAR) {
             if (t.smear_nk > 0) {
 #pragma unroll
                 for (int j = 0; j < QPL; ++j)
@@ -804,7 +828,7 @@ __device__ __forceinline__ QTables make_qtables(const ModelArgs &a, const double
         if (a.use_rowtab)
             rt = tab + Contrib<M>::table_doubles(a.int_div) + (size_t)(threadIdx.x >> 6) * Contrib<M>::ROWTAB * a.int_div;
     }
-    return QTables{q, q3inv, tab, rt, a.smear_locs_t, a.smear_cw, model_can_smear(M) ? a.smear_nk : 0, a.smear_stride};
+    return QTables{q, q3inv, tab, rt, a.smear_locs_t, a.smear_cw, Contrib<M>::CAN_SMEAR ? a.smear_nk : 0, a.smear_stride};
 }
 template <int QPL> struct RowEval<MCSAS_MODEL_SPHERE, QPL> {
     static __device__ __forceinline__ void run(const Contrib<MCSAS_MODEL_SPHERE> &c, const QTables &t, int lane,

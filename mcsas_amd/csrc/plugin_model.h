@@ -23,10 +23,11 @@ __device__ double mcsas_plugin_surface(const double *p);
 namespace mcsas {
 
 template <> struct Contrib<MCSAS_MODEL_PLUGIN> {
-    static constexpr int ROWTAB = 0;
+    static constexpr int ROWTAB = 0, INT_DIV_PARAM = -1, ROW_CLASS = 0;
+    static constexpr bool CAN_SMEAR = false;
     double p[MCSAS_MAX_PARAMS];
     double v, w, s;
-    static __device__ __forceinline__ int table_doubles(int) { return 0; }
+    static __host__ __device__ __forceinline__ int table_doubles(int) { return 0; }
     static __device__ __forceinline__ void fill_table(const ModelArgs &, double *, int, int) {}
     __device__ __forceinline__ void prepare(const ModelArgs &a, const double *row) {
         full_params(a, row, p);

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(64) void model_rows_kernel(ModelArgs m, int nq, con
     if (threadIdx.x == 0) { vset[i] = c.v; wset[i] = c.w; sset[i] = c.s; }
     for (int k = threadIdx.x; k < nq; k += WAVE) {
         double it;
-        if (model_can_smear(M) && m.smear_nk > 0) it = smeared_intensity<M>(c, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
+        if (Contrib<M>::CAN_SMEAR && m.smear_nk > 0) it = smeared_intensity<M>(c, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
         else it = c.intensity(q[k], tab);
         rows[(size_t)i * nq + k] = it;
     }
@@ -41,10 +41,10 @@ __global__ __launch_bounds__(64) void observability_kernel(ModelArgs m, int nq, 
     Contrib<M> cc;
     cc.prepare(m, row);
     const double vf = vol_frac[(size_t)c * R + r], A = scaling[r];
-    double best = INFINITY;
+    double best = __builtin_inf();
     for (int k = threadIdx.x; k < nq; k += WAVE) {
         double it;
-        if (model_can_smear(M) && m.smear_nk > 0) it = smeared_intensity<M>(cc, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
+        if (Contrib<M>::CAN_SMEAR && m.smear_nk > 0) it = smeared_intensity<M>(cc, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
         else it = cc.intensity(q[k], tab);
         double scaled = A * it;
         if (scaled != 0.) best = fmin(best, (sigma[k] * vf) / scaled);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void hist_rows_kernel(ModelArgs m, int nq, cons
     double *out = rows + ((size_t)rl * N + c) * nq;
     for (int k = threadIdx.x; k < nq; k += WAVE) {
         double it;
-        if (model_can_smear(M) && m.smear_nk > 0) it = smeared_intensity<M>(cc, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
+        if (Contrib<M>::CAN_SMEAR && m.smear_nk > 0) it = smeared_intensity<M>(cc, m.smear_locs_t, m.smear_cw, m.smear_nk, m.smear_stride, k, tab);
         else it = cc.intensity(q[k], tab);
         out[k] = it;
     }

@@ -16,6 +16,27 @@ from ._lib import MAX_ACTIVE, MAX_DEVICES, MAX_PARAMS, Problem, Result, as_dp, c
 
 MODEL_SPHERE, MODEL_CYL_ISO, MODEL_ELL_CS, MODEL_KHOLODENKO = 0, 1, 2, 3
 MODEL_ELL_ISO, MODEL_SPH_CS, MODEL_GAUSS_CHAIN, MODEL_LMA_SPHERE = 4, 5, 6, 7
+MODEL_PLUGIN0 = 64      # first id of a run-time model plug-in (include/mcsas_hip.h: MCSAS_MODEL_PLUGIN0)
+
+
+class PluginCompileError(ValueError):
+    """A model plug-in's HIP source does not compile; .log holds the compiler output."""
+    def __init__(self, message, log):
+        super().__init__(message + "\n" + log)
+        self.log = log
+
+
+def compile_plugin(source: str, tuning=False) -> int:
+    """Registers HIP source text for a model outside the built-in ones (mcsas_hip_plugin_compile, include/mcsas_hip.h: the
+    four functions mcsas_plugin_formfactor / _volume / _absvolume / _surface) and returns its model id.  Needs no GPU; the
+    same text gives the same id.  This is what stands in for the reference's model discovery (utils/findmodels.py:120-186)."""
+    lib = _lib.load(tuning)
+    mid = C.c_int32(-1)
+    rc = lib.mcsas_hip_plugin_compile(source.encode("utf-8"), C.byref(mid))
+    if rc != 0:
+        raise PluginCompileError(lib.mcsas_hip_last_error().decode("utf-8", "replace"),
+                                 lib.mcsas_hip_plugin_log().decode("utf-8", "replace"))
+    return int(mid.value)
 EXEC_AUTO, EXEC_WAVE, EXEC_WORKGROUP, EXEC_PIPELINE = 0, 1, 2, 3
 GEN_UNIFORM, GEN_EXP1, GEN_EXP2, GEN_EXP3 = 0, 1, 2, 3
 INT64_MAX = (1 << 63) - 1

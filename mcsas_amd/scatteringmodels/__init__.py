@@ -268,10 +268,16 @@ def setup_from_model(model, data=None) -> engine.ModelSetup:
     mid = getattr(model, "model_id", None)
     if mid is None:
         mid = MODEL_IDS.get(type(model).__name__)
+    if mid is None and isinstance(getattr(model, "hipSource", None), str):
+        # a model of the user's own (the reference: any models/*.py, utils/findmodels.py:120-186): its form factor as HIP
+        # source text, compiled at run time into the wave-per-chain kernel (engine.compile_plugin)
+        mid = engine.compile_plugin(model.hipSource)
     if mid is None:
-        raise NotImplementedError("model %s has no HIP kernel (supported: %s)"
-                                  % (type(model).__name__, ", ".join(MODEL_IDS)))
+        raise NotImplementedError("model %s has no HIP kernel (built in: %s; any other model needs a `hipSource` "
+                                  "attribute, see INTEGRATION.md)" % (type(model).__name__, ", ".join(MODEL_IDS)))
     params = list(model.params())
+    if len(params) > engine.MAX_PARAMS:
+        raise NotImplementedError("model %s has %d parameters, the C ABI carries %d" % (type(model).__name__, len(params), engine.MAX_PARAMS))
     values = np.array([float(p()) for p in params], dtype=float)
     active, lo, hi, kind, clo, chi, start = [], [], [], [], [], [], []
     for i, p in enumerate(params):

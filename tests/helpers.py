@@ -124,3 +124,49 @@ def traj_smearing(g):
     osm = oracle_smearing(kind, two_d, n, g["data_q"], **widths)
     _, psm = product_smearing(kind, two_d, n, g["data_q"], **widths)
     return osm, psm
+
+
+# ---- run-time model plug-ins (include/mcsas_hip.h: mcsas_hip_plugin_compile).  Two of the built-in models written again as
+# plug-in text, operation for operation (csrc/models.h: Contrib<MCSAS_MODEL_GAUSS_CHAIN>, Contrib<MCSAS_MODEL_SPH_CS>), so
+# that a plug-in chain can be compared bit for bit with its built-in twin and replayed against the reference's fixtures.
+PLUGIN_SOURCES = {
+    "gausschain": r"""
+// models/gaussianchain.py:54-66; p = (rg, bp, etas, k)
+__device__ double mcsas_plugin_volume(const double *p) { return p[3] * (p[0] * p[0]); }
+__device__ double mcsas_plugin_absvolume(const double *p) { return mcsas_plugin_volume(p); }
+__device__ double mcsas_plugin_surface(const double *p) { return 0.; }
+__device__ double mcsas_plugin_formfactor(double q, const double *p) {
+    const double beta = p[1] - mcsas_plugin_volume(p) * p[2];
+    const double x = q * p[0], u = x * x;
+    double f = sqrt(2.) * sqrt(expm1(-u) + u) / u;
+    f *= beta;
+    if (q <= 0.0) f = beta;
+    return f;
+}
+""",
+    "sphcs": r"""
+// models/sphericalcoreshell.py:50-77; p = (radius, t, eta_c, eta_s, eta_sol)
+__device__ double mcsas_plugin_volume(const double *p) { const double rt = p[0] + p[1]; return 4. / 3 * mcsas::PI * (rt * rt * rt); }
+__device__ double mcsas_plugin_absvolume(const double *p) { return mcsas_plugin_volume(p); }
+__device__ double mcsas_plugin_surface(const double *p) { return 0.; }
+__device__ double mcsas_plugin_formfactor(double q, const double *p) {
+    const double r = p[0], rt = p[0] + p[1];
+    const double vr = (4. / 3 * mcsas::PI * (r * r * r)) / (4. / 3 * mcsas::PI * (rt * rt * rt));
+    const double ds = p[3] - p[4], dc = p[3] - p[2];
+    double sn, cs;
+    const double xs = q * rt;
+    mcsas::sincos_fast(xs, &sn, &cs);
+    const double ks = mcsas::div_fast(ds * 3. * (sn - xs * cs), xs * xs * xs);
+    const double xc = q * r;
+    mcsas::sincos_fast(xc, &sn, &cs);
+    const double kc = mcsas::div_fast(dc * 3. * (sn - xc * cs), xc * xc * xc);
+    return ks - vr * kc;
+}
+""",
+}
+
+
+def plugin_twin(model, tag):
+    """The same configured model instance, but as a user's own class: no built-in kernel id, its form factor as HIP text."""
+    model.__class__ = type(type(model).__name__ + "AsPlugin", (type(model),), {"model_id": None, "hipSource": PLUGIN_SOURCES[tag]})
+    return model

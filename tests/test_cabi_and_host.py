@@ -201,3 +201,27 @@ def test_release_library_refuses_a_nonzero_reserved_word():
     assert lib.mcsas_hip_analyse(C.byref(prob.c), C.byref(res.c)) == -1
     tl = _lib.load(tuning=True)
     assert tl.mcsas_hip_is_tuning_build() == 1 and tl is not lib
+
+
+def test_model_plugins_compile_without_a_gpu_and_report_compiler_errors():
+    """mcsas_hip_plugin_compile: hiprtc builds the plug-in text against the kernel headers the library carries — no GPU, no source
+    tree; the same text gives the same id; a text that does not compile is refused with the compiler's message."""
+    from helpers import PLUGIN_SOURCES, make_models, plugin_twin
+    a = engine.compile_plugin(PLUGIN_SOURCES["gausschain"])
+    b = engine.compile_plugin(PLUGIN_SOURCES["sphcs"])
+    assert a >= engine.MODEL_PLUGIN0 and b >= engine.MODEL_PLUGIN0 and a != b
+    assert engine.compile_plugin(PLUGIN_SOURCES["gausschain"]) == a
+    with pytest.raises(engine.PluginCompileError) as e:
+        engine.compile_plugin(PLUGIN_SOURCES["gausschain"].replace("p[3] * (p[0] * p[0])", "p[3] * rg_squared"))
+    assert "rg_squared" in e.value.log and "plugin:" in e.value.log          # (line numbers refer to the plug-in text)
+    # host mirror: a model class of the user's own with a `hipSource` attribute flattens like a built-in one
+    m, _ = make_models("gausschain")
+    s0 = m.setup()
+    s1 = plugin_twin(m, "gausschain").setup()
+    assert s1.model_id == a and s0.model_id == engine.MODEL_GAUSS_CHAIN
+    assert np.array_equal(s0.params, s1.params) and s0.active_index == s1.active_index
+    # ... and one without it is still a loud error
+    class Nameless(mcsas_amd.scatteringmodels.SASModel):
+        parameters = ()
+    with pytest.raises(NotImplementedError):
+        Nameless().setup()

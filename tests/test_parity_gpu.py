@@ -975,3 +975,67 @@ def test_pipeline_geometry_follows_the_chain_count():
         plan = engine.Plan(mk.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st)
         assert plan.info["window"] == window, (reps, plan.info)
         plan.close()
+
+
+# ------------------------------------------------------------------------------ run-time model plug-ins
+@pytest.mark.parametrize("tag,name", [("gausschain", "g4_gausschain_q40.npz"), ("sphcs", "g4_sphcs_q40.npz")])
+def test_plugin_model_replays_the_reference_and_equals_its_built_in_twin(tag, name):
+    """A model that reaches the library as HIP source text (mcsas_hip_plugin_compile) runs the same wave-per-chain kernel as the
+    built-in ones: written operation for operation like its built-in twin it replays the reference's trajectory and is
+    bit-identical to the twin — chain results, ScatteringModel.calc and the histogram preparation alike."""
+    from helpers import plugin_twin
+    g, m, spec, st, ost = traj_setup(name)
+    q, I, sig = g["data_q"], g["data_I"], g["data_sigma"]
+    st.exec_mode, st.waves_per_chain = engine.EXEC_WAVE, 1
+    ref = engine.analyse(m.setup(FakeData(q)), q, I, sig, st, replay=g["stream"][None, :])
+    pset = np.array(ref.contribs[:, :, 0])
+    calc_ref = engine.model_calc(m.setup(), q, pset, st.comp_exp, want_rows=True)
+    prep_ref = engine.histogram_prep(m.setup(), q, I, sig, ref.contribs, st.comp_exp, st.find_background, st.positive_background)
+    plugin_twin(m, tag)
+    setup = m.setup(FakeData(q))
+    assert setup.model_id >= engine.MODEL_PLUGIN0
+    for cache in (1, 0):
+        st.cache_intensities = cache
+        res = engine.analyse(setup, q, I, sig, st, replay=g["stream"][None, :])
+        assert res.num_iter[0] == int(g["res_num_iter"]) and res.num_moves[0] == int(g["res_num_moves"])
+        np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
+        np.testing.assert_allclose(res.chisq[0], float(g["res_conval"]), rtol=1e-7)
+        if cache:
+            assert np.array_equal(res.contribs, ref.contribs) and np.array_equal(res.fit, ref.fit) and res.chisq[0] == ref.chisq[0]
+    for a, b in zip(engine.model_calc(setup, q, pset, st.comp_exp, want_rows=True), calc_ref):
+        assert np.array_equal(a, b)
+    for a, b in zip(engine.histogram_prep(setup, q, I, sig, ref.contribs, st.comp_exp, st.find_background, st.positive_background), prep_ref):
+        assert np.array_equal(a, b)
+    # the other execution modes have no plug-in kernels: refused, not silently replaced
+    st.exec_mode, st.waves_per_chain = engine.EXEC_PIPELINE, 0
+    with pytest.raises(mcsas_amd._lib.McSASHipError) as e:
+        engine.analyse(setup, q, I, sig, st, replay=g["stream"][None, :])
+    assert e.value.code == -1
+
+
+def test_plugin_model_through_the_mcsas_front_end():
+    """McSAS.calc() — analyse() + histogram() — with a model class of the user's own (`hipSource`), free-running: the same seed
+    gives the same result dictionary as the built-in twin."""
+    from helpers import plugin_twin
+    out = []
+    for as_plugin in (False, True):
+        m, _ = make_models("gausschain", [1e-9, 5e-8], [3e-8, 2e-7], [1, 0])
+        if as_plugin:
+            plugin_twin(m, "gausschain")
+        rng = np.random.default_rng(5)
+        q = np.geomspace(1e8, 4e9, 60)
+        pset = np.column_stack([rng.uniform(2e-9, 2e-8, 30), rng.uniform(6e-8, 1.5e-7, 30)])
+        base = m.calc(q, pset, 0.6666666).chisqrInt
+        I = base / base.max() + 1e-3
+        sig = 0.02 * I
+        algo = mcsas_amd.McSAS.factory()()
+        algo.numContribs.setValue(40); algo.numReps.setValue(4); algo.maxIterations.setValue(3000)
+        algo.convergenceCriterion.setValue(1e-3); algo.maxRetries.setValue(0); algo.showIncomplete.setValue(True)
+        algo.seed = 11
+        algo.model = m
+        algo.data = mcsas_amd.SASData(q, I, sig)
+        algo.calc()
+        out.append(algo.result[0])
+    a, b = out
+    assert np.array_equal(a["contribs"], b["contribs"]) and np.array_equal(a["fitMeasValMean"], b["fitMeasValMean"])
+    assert np.array_equal(a["scalingFactors"], b["scalingFactors"])
