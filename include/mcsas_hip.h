@@ -59,12 +59,15 @@ enum {
  * seed can take different turns at a numerically tied step (replacing one negligible contribution by another moves chi²
  * by less than its rounding error).  A repetition's result is reproducible for the same mode — whatever the number of
  * repetitions or devices beside it for rows without an integral (the pipeline's window does not depend on the chain count);
- * for rows with an integral the pipeline's window does follow the chain count (csrc/chain_pipe.h: pipe_geometry). */
+ * for rows with an integral the pipeline's window does follow the chain count (csrc/chain_pipe.h: pipe_geometry).
+ * q-points (the reference takes any data.count, mcsas.py:210): up to 1024 in every mode; 1025..16384 (un-binned data files,
+ * nBin = 0) one workgroup per chain with the q-points split over its waves (csrc/chain_wide.h: MCSAS_EXEC_WORKGROUP, and
+ * what MCSAS_EXEC_AUTO picks); up to 4096 MCSAS_EXEC_WAVE also runs; beyond 16384 MCSAS_EINVAL. */
 enum {
     MCSAS_EXEC_AUTO = 0,
     MCSAS_EXEC_WAVE = 1,      /* one wavefront per chain: many repetitions (>= ~1000) */
-    MCSAS_EXEC_WORKGROUP = 2, /* one workgroup per chain, speculative proposal window in LDS */
-    MCSAS_EXEC_PIPELINE = 3   /* producer kernels on every CU + one scan workgroup per chain: few repetitions */
+    MCSAS_EXEC_WORKGROUP = 2, /* one workgroup per chain: speculative proposal window in LDS (nq <= 1024), q-split (nq > 1024) */
+    MCSAS_EXEC_PIPELINE = 3   /* producer kernels on every CU + one scan workgroup per chain: few repetitions (nq <= 1024) */
 };
 
 enum {

@@ -3,7 +3,7 @@
 // mcsas.py:210).  Same chain as chain_wave.h (McSAS.mcFit, mcsas.py:287-439; retry loop of McSAS.analyse, :220-246), same
 // arithmetic per q-point; what differs is where a q-point lives and how the three weighted sums of a step are put together.
 //
-// Layout: NW = blockDim.x / 64 waves (<= 16), qpad = 64 * QPL * NW; wave v owns the q slice [64 QPL v, 64 QPL (v + 1)):
+// Layout: NW = blockDim.x / 64 waves (<= 8), qpad = 64 * QPL * NW; wave v owns the q slice [64 QPL v, 64 QPL (v + 1)):
 // q index i = 64 (QPL v + j) + lane, j = register slot.  ft, w, wI of the slice live in registers; q and 1/q^3 in LDS when
 // they fit beside the model's tables (ChainArgs::pad1 = 1), else they are read from HBM/L2 through the same pointers.
 // Per step: every wave evaluates its slice of the proposal's row, reads its slice of the `old` row from the row cache
@@ -16,7 +16,7 @@
 
 namespace mcsas {
 
-constexpr int WIDE_MAX_WAVES = 16;
+constexpr int WIDE_MAX_WAVES = 8;        // 2 waves per SIMD: the row evaluators keep their 256 registers (16 waves: 128, and the sphere's interleaved sincos spills)
 constexpr int WIDE_PART_DOUBLES = 2 * WIDE_MAX_WAVES * 4 + 8;       // partial sums [parity][wave][4], then the stop word
 
 // block-wide sums of three per-lane values, the same in every thread; `par` alternates per call

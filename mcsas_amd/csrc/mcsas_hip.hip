@@ -21,6 +21,7 @@
 #include "small_kernels.h"   // model_rows_kernel, observability_kernel, hist_rows_kernel
 #include "chain_wg.h"   // WgGeom / wg_geometry only; the kernels are instantiated in kern_*.hip
 #include "chain_pipe.h" // PipeArgs / pipe_geometry only
+#include "chain_wide.h" // WIDE_* constants only
 #include "auto_table.h" // measured rates of the execution modes (tools/make_auto_table.py)
 #include "model_list.h" // MCSAS_FOR_MODELS: the built-in models
 
@@ -433,6 +434,7 @@ struct mcsas_plan {
     ChainArgs args;
     SmearDev smear;                     // device copy of the smearing tables (empty when off)
     int qpl = 0, waves = 1, use_cache = 1, dev = 0;
+    bool wide = false;                  // more than 1024 q-points, one workgroup per chain with the q-points split over its waves (chain_wide.h)
     size_t lds_bytes = 0;
     double *d_q = nullptr, *d_w = nullptr, *d_wI = nullptr, *d_I = nullptr, *d_q3inv = nullptr;
     double *d_rset = nullptr, *d_cache = nullptr, *d_fit = nullptr, *d_replay = nullptr;
@@ -461,7 +463,7 @@ struct mcsas_plan {
 };
 
 // kernel lookups, one translation unit per model (kern_wave.hip / kern_wg.hip)
-#define DECL_K(m) void *mcsas_wave_kernel_m##m(int, bool); void *mcsas_wg_kernel_m##m(int); void *mcsas_pipe_tick_kernel_m##m(int);
+#define DECL_K(m) void *mcsas_wave_kernel_m##m(int, bool); void *mcsas_wg_kernel_m##m(int); void *mcsas_wide_kernel_m##m(int); void *mcsas_pipe_tick_kernel_m##m(int);
 MCSAS_FOR_MODELS(DECL_K)
 #undef DECL_K
 void *mcsas_pipe_reset_kernel();
@@ -478,6 +480,14 @@ static void *pipe_tick_kernel_for(int model, int qpl) {
 static void *wave_kernel_for(int model, int qpl, bool cache) {
     switch (model) {
 #define CASE_K(m) case m: return mcsas_wave_kernel_m##m(qpl, cache);
+        MCSAS_FOR_MODELS(CASE_K)
+#undef CASE_K
+        default: return nullptr;
+    }
+}
+static void *wide_kernel_for(int model, int qpl) {
+    switch (model) {
+#define CASE_K(m) case m: return mcsas_wide_kernel_m##m(qpl);
         MCSAS_FOR_MODELS(CASE_K)
 #undef CASE_K
         default: return nullptr;
@@ -572,12 +582,27 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
 
     // q slots per lane: power of two so the kernels are fully unrolled
     int qpl = 1;
-    while (qpl * WAVE < p->nq) qpl *= 2;
-    // up to 1024 q-points every execution mode has kernels (q slots per lane 1..16); 1025..4096 (un-binned data,
-    // nBin = 0) run one wavefront per chain with 32 / 64 slots per lane and cached rows
-    if (qpl > 64) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 4096 is not supported", p->nq); }
-    const bool wide_q = qpl > 16;
-    const int qpad = qpl * WAVE;
+    while (qpl * WAVE < p->nq && qpl < 64) qpl *= 2;
+    // up to 1024 q-points every execution mode has kernels (q slots per lane 1..16).  More (un-binned data, nBin = 0):
+    // one workgroup per chain with the q-points split over up to 8 waves (chain_wide.h; 8 / 16 / 32 slots per lane:
+    // up to 4096 / 8192 / 16384 q-points) — MCSAS_EXEC_WORKGROUP, and what MCSAS_EXEC_AUTO picks; up to 4096 q-points
+    // MCSAS_EXEC_WAVE still runs one wavefront per chain with 32 / 64 slots per lane
+    const bool wide_q = p->nq > 16 * WAVE;
+    const bool plugin_early = is_plugin_model(p->model_id);
+    bool wide = false;
+    int wide_waves = 0;
+    if (wide_q && !plugin_early) {
+        const bool wave_asked = p->exec_mode == MCSAS_EXEC_WAVE || (p->exec_mode == MCSAS_EXEC_AUTO && p->waves_per_chain == 1);
+        if (p->exec_mode == MCSAS_EXEC_PIPELINE) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 1024: the pipeline has no kernels for it (exec_mode 0, 1 or 2)", p->nq); }
+        if (p->nq > WIDE_MAX_WAVES * WAVE * 32) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 16384 is not supported", p->nq); }
+        if (wave_asked && p->nq > 64 * WAVE) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 4096 runs one workgroup per chain only (exec_mode 0 or 2)", p->nq); }
+        if (!wave_asked) {
+            wide = true;
+            qpl = p->nq <= 8 * WAVE * WIDE_MAX_WAVES ? 8 : (p->nq <= 16 * WAVE * WIDE_MAX_WAVES ? 16 : 32);
+            wide_waves = (p->nq + qpl * WAVE - 1) / (qpl * WAVE);
+        }
+    }
+    const int qpad = wide ? qpl * WAVE * wide_waves : qpl * WAVE;
     rc = pl->smear.upload(p, qpad, &margs);
     if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
     const int tab_shared = table_doubles_host(p->model_id, margs.int_div), tab_row = rowtab_doubles_host(p->model_id, margs.int_div);
@@ -635,15 +660,11 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             }
         }
     }
-    if (wide_q) {
-        if (mode != MCSAS_EXEC_AUTO && mode != MCSAS_EXEC_WAVE && p->exec_mode != MCSAS_EXEC_AUTO) {
-            mcsas_hip_plan_destroy(pl);
-            return fail(MCSAS_EINVAL, "nq %d > 1024 runs one wavefront per chain only (exec_mode %d asked)", p->nq, p->exec_mode);
-        }
-        mode = MCSAS_EXEC_WAVE;
-    }
+    if (wide) { mode = MCSAS_EXEC_WORKGROUP; waves = wide_waves; }
+    else if (wide_q) mode = MCSAS_EXEC_WAVE;
     if (mode == MCSAS_EXEC_WORKGROUP && waves < 2) waves = WG_MAX_WAVES;
     if (mode != MCSAS_EXEC_WORKGROUP) waves = 1;
+    pl->wide = wide;
     if (mode < MCSAS_EXEC_WAVE || mode > MCSAS_EXEC_PIPELINE) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "exec_mode %d", mode); }
     pl->qpl = qpl; pl->waves = waves; pl->mode = mode;
 
@@ -679,7 +700,9 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
 
     // per-contribution intensity rows: the speculative kernels add two windows of spare row slots
     int cache_rows = (int)N;
-    if (mode == MCSAS_EXEC_WORKGROUP) {
+    if (wide) {
+        // q-split workgroup: no speculation, rows [N][qpad] like the wave kernel
+    } else if (mode == MCSAS_EXEC_WORKGROUP) {
         int rcg = wg_geometry(p->nq, (int)N, TABD(waves), waves, &pl->wg);
         if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: needs 2*window <= n_contrib and the window in LDS (nq=%d, n_contrib=%d, waves=%d)", p->nq, (int)N, waves); }
         cache_rows = (int)N + 2 * pl->wg.window;
@@ -734,6 +757,13 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             rc = plugin_wave_function(p->model_id, qpl, use_cache != 0, &pl->plugin_fn);     // (compiled on first use of this q count)
             if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
         } else if (!wave_kernel_for(p->model_id, qpl, use_cache)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no kernel for model %d qpl %d", p->model_id, qpl); }
+    } else if (wide) {
+        // partial sums, the model's tables and one row scratch per wave; q and 1/q^3 as well when they fit (ChainArgs::pad1)
+        const size_t base = sizeof(double) * ((size_t)WIDE_PART_DOUBLES + TABD(waves));
+        const size_t with_q = base + sizeof(double) * 2 * (size_t)qpad;
+        a.pad1 = with_q <= 150 * 1024 ? 1 : 0;
+        pl->lds_bytes = a.pad1 ? with_q : base;
+        if (!wide_kernel_for(p->model_id, qpl)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no q-split kernel for model %d qpl %d", p->model_id, qpl); }
     } else if (mode == MCSAS_EXEC_WORKGROUP) {
         pl->lds_bytes = pl->wg.lds_bytes;
     } else {
@@ -858,6 +888,9 @@ extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
     if (pl->mode == MCSAS_EXEC_WAVE) {
         fn = wave_kernel_for(pl->prob.model_id, pl->qpl, pl->use_cache);
         block = dim3(WAVE);
+    } else if (pl->wide) {
+        fn = wide_kernel_for(pl->prob.model_id, pl->qpl);
+        block = dim3(WAVE * pl->waves);
     } else {
         fn = wg_kernel_for(pl->prob.model_id, pl->qpl);
         block = dim3(WAVE * pl->waves);
@@ -868,6 +901,9 @@ extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
     HIPCHK(hipEventRecord(pl->ev0, st));
     if (pl->mode == MCSAS_EXEC_WAVE) {
         HIPCHK(hipLaunchKernel(fn, grid, block, kargs, pl->lds_bytes, st));
+    } else if (pl->wide) {
+        void *kargs3[] = {(void *)&pl->args, (void *)&pl->d_q3inv};
+        HIPCHK(hipLaunchKernel(fn, grid, block, kargs3, pl->lds_bytes, st));
     } else {
         void *kargs2[] = {(void *)&pl->args, (void *)&pl->wg};
         HIPCHK(hipLaunchKernel(fn, grid, block, kargs2, pl->lds_bytes, st));
@@ -970,7 +1006,7 @@ extern "C" int mcsas_hip_plan_info(mcsas_plan *pl, int32_t info[8]) {
     if (!pl || !info) return fail(MCSAS_EINVAL, "null argument");
     memset(info, 0, sizeof(int32_t) * 8);
     info[0] = pl->mode; info[1] = pl->waves; info[2] = pl->qpl;
-    info[3] = pl->mode == MCSAS_EXEC_PIPELINE ? pl->pipe.g.kb : (pl->mode == MCSAS_EXEC_WORKGROUP ? pl->wg.window : 1);
+    info[3] = pl->mode == MCSAS_EXEC_PIPELINE ? pl->pipe.g.kb : (pl->mode == MCSAS_EXEC_WORKGROUP && !pl->wide ? pl->wg.window : 1);
     info[4] = pl->mode == MCSAS_EXEC_PIPELINE ? pl->ticks_launched + 2 : 1;
     info[5] = pl->use_cache;
     return MCSAS_OK;

@@ -420,8 +420,11 @@ EDGE = [  # (nq, n_contrib, max_iter, reps)
     (64, 40, 130, 3), (65, 33, 97, 2), (7, 16, 50, 2), (130, 2, 40, 2), (512, 1, 10, 2), (100, 50, 0, 2),
     (300, 200, 700, 5), (1024, 64, 90, 2),
     # more than 1024 q-points (un-binned data files, nBin = 0: the reference takes any data.count, mcsas.py:210): one
-    # wavefront per chain with 32 / 64 q slots per lane; the workgroup and pipeline modes refuse these shapes
+    # workgroup per chain with the q-points split over its waves (chain_wide.h: exec_mode 2 and what auto picks), or — up to
+    # 4096 — one wavefront per chain with 32 / 64 q slots per lane (exec_mode 1); the pipeline refuses these shapes
     (1500, 40, 120, 2), (2048, 33, 70, 2), (3000, 24, 50, 1), (4096, 20, 40, 1),
+    # ... and beyond 4096 (16 / 32 q slots per lane in the q-split kernel), up to 16384
+    (5000, 20, 40, 2), (9000, 16, 24, 1), (16384, 16, 12, 1),
 ]
 
 
@@ -441,15 +444,19 @@ def test_edge_shapes_all_modes_agree_with_oracle(nq, n, steps, reps):
         try:
             res = engine.analyse(m.setup(), q, I, sig, st)
         except mcsas_amd._lib.McSASHipError as e:
-            assert e.code == -1 and mode in (engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE)
+            assert e.code == -1 and (mode in (engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE) or (mode == engine.EXEC_WAVE and nq > 4096))
+            assert not (mode == engine.EXEC_WORKGROUP and nq > 1024)          # the q-split kernel takes every wide shape
             continue
         ran += 1
+        if nq > 1024 and mode in (engine.EXEC_WORKGROUP, engine.EXEC_AUTO):
+            info = engine.Plan(m.setup(), q, I, sig, st).info
+            assert info["exec_mode"] == "workgroup" and info["q_per_lane"] * 64 * info["waves_per_chain"] >= nq
         for r in range(reps):
             assert res.num_iter[r] == ref[r].num_iter and res.num_moves[r] == ref[r].num_moves
             np.testing.assert_allclose(res.contribs[:, :, r], ref[r].rset, rtol=1e-12)
             np.testing.assert_allclose(res.chisq[r], ref[r].conval, rtol=1e-7)
             np.testing.assert_allclose(res.fit[:, r], ref[r].fit, rtol=1e-7)
-    assert ran >= 2                                    # wavefront mode and auto always run
+    assert ran >= 2                                    # auto always runs, and wavefront or q-split workgroup mode
 
 
 @pytest.mark.parametrize("mode", [engine.EXEC_WAVE, engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE])
@@ -912,13 +919,13 @@ def test_no_active_parameter_returns_the_model_intensity():
         engine.Plan(m.setup(), q, I, sig, st)
 
 
-def test_more_than_4096_q_points_is_refused_loudly():
-    q, I, sig = _synthetic(4100)
+def test_more_than_16384_q_points_is_refused_loudly():
+    q, I, sig = _synthetic(16385)
     m, _ = make_models("sphere", [np.pi / q.max()], [np.pi / q.min()])
     st = engine.Settings(n_contrib=20, n_reps=1, max_iter=10, conv_crit=0.0, max_retries=0)
     with pytest.raises(mcsas_amd._lib.McSASHipError) as e:
         engine.analyse(m.setup(), q, I, sig, st)
-    assert e.value.code == -1 and "4096" in str(e.value)
+    assert e.value.code == -1 and "16384" in str(e.value)
 
 
 def test_pipeline_tuning_variants_replay_the_reference():
@@ -1039,3 +1046,28 @@ def test_plugin_model_through_the_mcsas_front_end():
     a, b = out
     assert np.array_equal(a["contribs"], b["contribs"]) and np.array_equal(a["fitMeasValMean"], b["fitMeasValMean"])
     assert np.array_equal(a["scalingFactors"], b["scalingFactors"])
+
+
+@pytest.mark.parametrize("tag", ["cyl_aspect", "kholodenko", "lmasphere"])
+def test_wide_q_workgroup_kernel_with_integral_models_and_smearing_matches_the_wave_kernel(tag):
+    """More than 1024 q-points with rows that cost an orientation / contour integral (per-wave row tables in the q-split
+    workgroup) and with beam-profile smearing: the same chains as one wavefront per chain — the sums are put together in another
+    order, so decisions and parameter sets must agree and chi-squared to rounding."""
+    nq = {"cyl_aspect": 1300, "kholodenko": 1100, "lmasphere": 1500}[tag]
+    q, I, sig = _synthetic(nq)
+    lo, hi = RANDOM_RANGES[tag]
+    kw = {"intDiv": 20.} if tag == "cyl_aspect" else {}
+    m, spec = make_models(tag, lo, hi, **kw)
+    smear = None
+    if tag == "lmasphere":
+        d, _ = product_smearing("trapezoid", False, 15, q, I, sig, umbra=2e-3 * q.max(), penumbra=4e-3 * q.max())
+        smear = d.smearArgs(m)
+    out = {}
+    for mode in (engine.EXEC_WAVE, engine.EXEC_WORKGROUP):
+        st = engine.Settings(n_contrib=24, n_reps=3, max_iter=60, conv_crit=1e-9, max_retries=0, seed=9, exec_mode=mode)
+        out[mode] = engine.analyse(m.setup(), q, I, sig, st, smear=smear)
+    a, b = out[engine.EXEC_WAVE], out[engine.EXEC_WORKGROUP]
+    assert (a.num_iter == 60).all() and np.array_equal(a.num_moves, b.num_moves) and a.num_moves.sum() > 0
+    np.testing.assert_array_equal(a.contribs, b.contribs)
+    np.testing.assert_allclose(a.chisq, b.chisq, rtol=1e-10)
+    np.testing.assert_allclose(a.fit, b.fit, rtol=1e-10)
