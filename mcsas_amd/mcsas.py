@@ -90,7 +90,7 @@ class McSAS(object):
         if not self.model.paramCount():
             logging.warning("No parameters to analyse given! Breaking up.")
             return
-        self.analyse()
+        self.analyse(replay=kwargs.get("replay"))            # (replay: tests feed the uniform stream the reference consumed)
         if not len(self.result):
             return
         self.histogram()

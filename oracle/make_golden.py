@@ -854,6 +854,51 @@ def gen_quickstart(seed=3001):
           (wall, out["numIter"], res["scaling"], res["background"]))
 
 
+def gen_series(seed=3101):
+    """The computational core of the series Calculator (gui/calc.py:271-349): the SAME algorithm and model objects run calc() on
+    one data set after the other, and after each one every histogram of every active parameter contributes
+    (seriesKeyValue, hist.moments.fields) to the series table under (parameter, range, weighting) (_updateSeries :331-349).
+    Two data sets here — the quick-start file and a synthetic tri-modal sphere curve (64 q) — drawn from ONE global stream
+    (the second calc() continues where the first stopped), fixed budgets so that every repetition runs its 200 steps.
+    Stored: both data sets' vectors, the stream, where each calc() started in it, each result and the series table."""
+    d1 = loaddatafile("/root/reference/testdata/quickstartdemo1.csv").getDataObj()
+    d2 = sasdata(*synthetic_sphere_data(64, seed=77, qmin=0.02, qmax=2.0))
+    keys = [10.0, 25.0]
+    m = Sphere(); m.radius.setActiveRange(tuple(d1.sphericalSizeEst()))
+    lo, hi = m.radius.activeRange()
+    m.radius.histograms().append(Histogram(m.radius, lo, hi, binCount=16, xscale='log', yweight='vol'))
+    m.radius.histograms().append(Histogram(m.radius, lo, 0.5 * hi, binCount=8, xscale='lin', yweight='num'))
+    algo = new_algo(numContribs=60, numReps=2, maxIterations=200, convergenceCriterion=1e-9, maxRetries=0, showIncomplete=True)
+    algo.model = m
+    quiet_logging(None)
+    np.random.seed(seed)
+    long = np.random.RandomState(seed).random_sample(200000)
+    out = dict(lo=lo, hi=hi, keys=np.array(keys), seed=seed)
+    series = {}
+    starts = [0]
+    for i, d in enumerate((d1, d2)):
+        for k, v in data_vectors(d).items():
+            out["d%d_%s" % (i, k)] = v
+        algo.data = d
+        algo.calc()
+        res = algo.result[0]
+        out["d%d_contribs" % i] = np.array(res["contribs"]); out["d%d_numIter" % i] = float(res["numIter"])
+        out["d%d_scaling" % i] = np.array(res["scaling"]); out["d%d_background" % i] = np.array(res["background"])
+        for h in m.radius.histograms():                      # _updateSeries
+            uid = (h.param.name(),) + tuple(h.xrange) + (h.yweight,)
+            series.setdefault(uid, []).append((keys[i], np.array(h.moments.fields, dtype=float)))
+        st = np.random.get_state()
+        nxt = np.random.random_sample()
+        np.random.set_state(st)
+        starts.append(int(np.nonzero(long == nxt)[0][0]))
+    out["starts"] = np.array(starts); out["stream"] = long[:starts[-1] + 8]
+    for j, (uid, rows) in enumerate(series.items()):
+        out["s%d_uid" % j] = np.array([uid[1], uid[2]]); out["s%d_weight" % j] = uid[3]
+        out["s%d_keys" % j] = np.array([r[0] for r in rows]); out["s%d_moments" % j] = np.stack([r[1] for r in rows])
+    np.savez_compressed(os.path.join(OUT, "g15_series.npz"), **out)
+    print("G15 series written: draws per data set %s, moments %s" % (np.diff(starts), out["s0_moments"][:, 0]))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     quiet_logging(None)
@@ -879,6 +924,8 @@ if __name__ == "__main__":
         gen_param_declarations()
     if "kho5" in which:
         gen_kholodenko_config5()
+    if "series" in which:
+        gen_series()
     if "quickstart" in which or not sys.argv[1:]:
         gen_quickstart()
     if "long" in which or not sys.argv[1:]:

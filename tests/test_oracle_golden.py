@@ -304,3 +304,22 @@ def test_c_oracle_philox_and_threads_match_numpy_oracle():
         assert one.num_moves[r] == ref.num_moves
         np.testing.assert_allclose(one.contribs[:, 0, r], ref.rset[:, 0], rtol=1e-15)
         np.testing.assert_allclose(one.chisq[r], ref.conval, rtol=1e-9)
+
+
+def test_g15_series_two_data_sets_from_one_stream():
+    """The series Calculator's core (gui/calc.py:271-349): calc() on one data set after the other, ONE global random stream.
+    The oracle, fed the reference's stream, reproduces each data set's parameter sets and leaves the stream where the
+    reference's next calc() picked it up (maxRetries is clipped to its valueRange's minimum of 1: two attempts per repetition)."""
+    g = load("g15_series.npz")
+    m, spec = make_models("sphere", [float(g["lo"])], [float(g["hi"])])
+    ost = O.Settings(n_contrib=60, n_reps=2, max_iter=200, conv_crit=1e-9, max_retries=1, show_incomplete=True)
+    stream = O.ReplayStream(g["stream"])
+    for i in range(2):
+        pre = "d%d_" % i
+        assert stream.pos == int(g["starts"][i])
+        res, info = O.analyse(spec, g[pre + "q"], g[pre + "I"], g[pre + "sigma"], g[pre + "f_limit"], g[pre + "x0_limit"], ost,
+                              stream, method="closed")
+        np.testing.assert_allclose(res["contribs"], g[pre + "contribs"], rtol=1e-12)
+        assert res["numIter"] == float(g[pre + "numIter"])
+        np.testing.assert_allclose(res["scaling"], g[pre + "scaling"], rtol=1e-6)
+    assert stream.pos == int(g["starts"][2])

@@ -1071,3 +1071,49 @@ def test_wide_q_workgroup_kernel_with_integral_models_and_smearing_matches_the_w
     np.testing.assert_array_equal(a.contribs, b.contribs)
     np.testing.assert_allclose(a.chisq, b.chisq, rtol=1e-10)
     np.testing.assert_allclose(a.fit, b.fit, rtol=1e-10)
+
+
+def test_run_series_replays_the_reference_series():
+    """mcsas_amd.run_series against the reference's own series run (fixture g15, oracle/make_golden.py gen_series: the same
+    algorithm and model objects, calc() on two data sets drawing from one global stream, the series table of
+    gui/calc.py:331-349): each data set's repetitions replay their slices of the reference's stream and every entry of the
+    table — (series key, histogram moments) per (parameter, range, weighting) — comes out as the reference's."""
+    g = load("g15_series.npz")
+    lo, hi = float(g["lo"]), float(g["hi"])
+    m, spec = make_models("sphere", [lo], [hi])
+    m.radius.histograms().append(mcsas_amd.Histogram(m.radius, lo, hi, binCount=16, xscale='log', yweight='vol'))
+    m.radius.histograms().append(mcsas_amd.Histogram(m.radius, lo, 0.5 * hi, binCount=8, xscale='lin', yweight='num'))
+    ost = O.Settings(n_contrib=60, n_reps=2, max_iter=200, conv_crit=1e-9, max_retries=1, show_incomplete=True)
+    stream = O.ReplayStream(g["stream"])
+    datasets, replays = [], []
+    for i in range(2):
+        pre = "d%d_" % i
+        _, info = O.analyse(spec, g[pre + "q"], g[pre + "I"], g[pre + "sigma"], g[pre + "f_limit"], g[pre + "x0_limit"], ost,
+                            stream, method="closed")
+        L = max(x["end"] - x["start"] for x in info) + 8
+        replays.append(np.stack([np.resize(g["stream"][x["start"]:], L) for x in info]))
+        datasets.append(mcsas_amd.SASData(g[pre + "q"], g[pre + "I"], g[pre + "sigma"], f_limit=g[pre + "f_limit"]))
+    algo = mcsas_amd.McSAS.factory()()
+    algo.numContribs.setValue(60); algo.numReps.setValue(2); algo.maxIterations.setValue(200)
+    algo.convergenceCriterion.setValue(1e-9); algo.maxRetries.setValue(0); algo.showIncomplete.setValue(True)
+    assert algo.maxRetries() == 1                        # clipped into its valueRange like the reference's (mcsasparameters.json:71-74)
+    algo.model = m
+    results, series = mcsas_amd.run_series(algo, datasets, keys=list(g["keys"]), replays=replays)
+    for i, res in enumerate(results):
+        pre = "d%d_" % i
+        np.testing.assert_allclose(res["contribs"], g[pre + "contribs"], rtol=1e-12)
+        assert res["numIter"] == float(g[pre + "numIter"])
+        np.testing.assert_allclose(res["scaling"], g[pre + "scaling"], rtol=1e-6)
+    assert len(series) == 2
+    for j, (uid, rows) in enumerate(series.items()):
+        assert uid[0] == "radius" and uid[3] == str(g["s%d_weight" % j])
+        np.testing.assert_allclose(uid[1:3], g["s%d_uid" % j], rtol=1e-15)
+        assert [r[0] for r in rows] == list(g["s%d_keys" % j])
+        got = np.array([r[1] for r in rows], dtype=float)
+        # (value, uncertainty) pairs of mean / variance / skew / kurtosis: the values are sums over all contributions; their
+        # uncertainties are standard deviations over TWO repetitions of nearly equal numbers
+        np.testing.assert_allclose(got[:, 0::2], g["s%d_moments" % j][:, 0::2], rtol=1e-6)
+        want = g["s%d_moments" % j]
+        for r in range(want.shape[0]):
+            for c in range(1, want.shape[1], 2):
+                np.testing.assert_allclose(got[r, c], want[r, c], rtol=1e-4, atol=1e-9 * abs(want[r, c - 1]))
