@@ -17,9 +17,9 @@ equal --gpus.  Weak scaling: every rank runs the config's per-GPU repetitions; s
 repetitions (50 / 200 / 400 / 100) are sharded over the ranks (mcsas_amd.dist.shard_reps); chain id = global
 repetition index either way, and one all-gather (RCCL) per launch assembles the results.
 
-Prints ONE JSON line (rank 0); besides the contract's keys: `roofline` (the resource the counters name for this kernel —
-fp64 vector issue — with the SURVEY 8d byte model against the HBM peak kept beside it as `algorithmic_hbm` and the
-memory-side traffic of the committed FETCH/WRITE passes as `traffic`), `launch_ms` (min / median / max), `configs`
+Prints ONE JSON line (rank 0); besides the contract's keys: `roofline` (the SURVEY 8d byte model — 40 Q bytes per MC step —
+against the HBM peak, with the memory-side traffic of the committed FETCH/WRITE passes as `traffic`), `roofline_valu` (the
+resource the counters name for these kernels: fp64 vector issue), `launch_ms` (min / median / max), `configs`
 (configs 3-5 at their per-GPU repetition counts, each sustained over >= 1 s of back-to-back launches),
 `convergence_run` (criterion 1 as BASELINE names it), `quickstart` (the reference's published workload end to end) and
 `cpu_baseline`.
@@ -352,16 +352,13 @@ def main():
             pv = json.load(open(ij)).get(str(args.config)) if os.path.exists(ij) else None
             if pv and info["exec_mode"] == "pipeline":
                 rate = pv["valu_wave_instr_per_mc_step"] * steps_per_launch / launch_s
-                out["roofline"] = {"bound": "valu", "achieved": rate / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9,
-                                   "unit": "G wave-instr/s", "frac": rate / FP64_VECTOR_PEAK_INSTR, "traffic": traffic,
-                                   "traffic_unit": "GB/s", "traffic_source": source,
-                                   "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
-                                   "source": "from_profile: profiles/r03_valu_per_step.json (SQ_INSTS_VALU pass, commit %s)" % pv.get("commit", "?"),
-                                   "note": "fp64 vector issue: 1024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz; achieved = "
-                                           "SQ_INSTS_VALU per MC step (committed counter pass) x MC steps per launch / mean HIP-event time of a launch",
-                                   "algorithmic_hbm": algorithmic}
-            else:
-                out["roofline"] = dict(algorithmic, traffic=traffic, traffic_source=source)
+                out["roofline_valu"] = {"bound": "valu", "achieved": rate / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9,
+                                        "unit": "G wave-instr/s", "frac": rate / FP64_VECTOR_PEAK_INSTR,
+                                        "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
+                                        "source": "from_profile: profiles/r03_valu_per_step.json (SQ_INSTS_VALU pass, commit %s)" % pv.get("commit", "?"),
+                                        "note": "fp64 vector issue: 1024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz; achieved = "
+                                                "SQ_INSTS_VALU per MC step (committed counter pass) x MC steps per launch / mean HIP-event time of a launch"}
+            out["roofline"] = dict(algorithmic, traffic=traffic, traffic_unit="GB/s", traffic_source=source)
         # outside the timed region: the same repetitions run the way McSAS.analyse runs them — convergenceCriterion 1 (BASELINE),
         # maxIterations 1e5, one attempt — -> final chi² and how many got there.  (With 1 % noise on the synthetic curve 400
         # spheres plateau near chi² 1.15: the criterion is out of reach on THIS data set and every chain runs its full budget;
@@ -443,15 +440,12 @@ def other_configs(dev_index, seconds=1.0):
         pv = prof.get(str(cfg))
         tr = traf.get(str(cfg))
         traffic = (tr["fetch_bytes_per_mc_step"] + tr["write_bytes_per_mc_step"]) * rate / 1e9 if tr else None
+        e["roofline"] = dict(alg, traffic=traffic, traffic_unit="GB/s")
         if pv:
             r = pv["valu_wave_instr_per_mc_step"] * rate
-            e["roofline"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
-                             "frac": r / FP64_VECTOR_PEAK_INSTR, "traffic": traffic, "traffic_unit": "GB/s",
-                             "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
-                             "source": "from_profile: profiles/r03_valu_per_step.json / r03_pmc_traffic.json (commit %s)" % pv.get("commit", "?"),
-                             "algorithmic_hbm": alg}
-        else:
-            e["roofline"] = dict(alg, traffic=traffic)
+            e["roofline_valu"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
+                                  "frac": r / FP64_VECTOR_PEAK_INSTR, "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
+                                  "source": "from_profile: profiles/r03_valu_per_step.json / r03_pmc_traffic.json (commit %s)" % pv.get("commit", "?")}
         out[str(cfg)] = e
     return out
 
