@@ -15,7 +15,8 @@ min / median / max.
 forwards their output and exits with their code; under an external launcher (WORLD_SIZE set) the world size must
 equal --gpus.  Weak scaling: every rank runs the config's per-GPU repetitions; strong scaling: the config's total
 repetitions (50 / 200 / 400 / 100) are sharded over the ranks (mcsas_amd.dist.shard_reps); chain id = global
-repetition index either way, and one all-gather (RCCL) per launch assembles the results.
+repetition index either way; nothing in an analysis needs another rank (no data-path collective): one all-gather (RCCL)
+after the timed region puts the last analysis together.
 
 Prints ONE JSON line (rank 0); besides the contract's keys: `roofline` (the SURVEY 8d byte model — 40 Q bytes per MC step —
 against the HBM peak, with the memory-side traffic of the committed FETCH/WRITE passes as `traffic`), `roofline_valu` (the
@@ -208,6 +209,7 @@ def main():
                     help="skip the untimed run-to-convergence (profiling: only the timed launches reach the profiler)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of configs 3-5")
     ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic role ablation (invalid results)")
+    ap.add_argument("--inflight", type=int, default=2, help="analyses in flight on this rank (plans taking turns on one stream); 1 = one after the other")
     ap.add_argument("--dump", default="", help="rank 0: write the gathered arrays of the last launch to this .npz (tests)")
     args = ap.parse_args()
 
@@ -265,21 +267,50 @@ def main():
                              max_retries=0, seed=20250101, rep_offset=first, device=dev_index,
                              waves_per_chain=args.waves, exec_mode=args.mode, debug_flags=args.debug_flags)
         plan = engine.Plan(setup, q, I, sigma, st)
+    # Analyses in flight: every launch is a complete analyse() of this rank's repetitions whose results come back to the host;
+    # with TWO plans (two sets of workspaces) taking turns on one stream the next analysis is already queued while the
+    # previous one's results are fetched and unpacked, so the GPU does not idle for the host (a series of data sets,
+    # mcsas_amd.run_series, is the use case).  --inflight 1: strictly one after the other.
+    plans = [plan] + ([] if dry else [engine.Plan(setup, q, I, sigma, st) for _ in range(max(args.inflight, 1) - 1)])
 
     launch_ms = []
     gathered = {}
+    pending = []
+    state = {"mc": 0, "res": None, "n": 0}
+
+    def retire():
+        pl = pending.pop(0)
+        res = pl.fetch()
+        launch_ms.append(pl.last_ms)
+        state["mc"] += pl.total_steps
+        state["res"] = res
+        return res
 
     def one_launch(seed):
-        plan.reseed(seed, first)
-        plan.launch()
-        res = plan.fetch()
-        launch_ms.append(plan.last_ms)
-        if use_dist or args.dump:
+        pl = plans[state["n"] % len(plans)]
+        state["n"] += 1
+        if pl in pending:                                 # (its previous analysis must be home before it is started again)
+            while pl in pending:
+                retire()
+        pl.reseed(seed, first)
+        pl.launch()
+        pending.append(pl)
+        while len(pending) >= len(plans):
+            retire()
+
+    def drain():
+        while pending:
+            retire()
+
+    def gather_last():
+        # the ranks' blocks of the LAST analysis put together (one RCCL all-gather, outside the timed region: the repetitions
+        # are independent and nothing in an analysis needs another rank's results)
+        res = state["res"]
+        if res is not None and (use_dist or args.dump):
             local = dict(contribs=np.moveaxis(res.contribs, 2, 0), chisq=res.chisq[:, None],
                          scaling=res.scaling[:, None], background=res.background[:, None], fit=res.fit.T)
             gathered.clear()
             gathered.update(mdist.gather_results(local, n_total) if use_dist else {k: np.asarray(v) for k, v in local.items()})
-        return res
 
     def barrier():
         if use_dist:
@@ -291,16 +322,19 @@ def main():
     for w in range(args.warmup):
         for _ in range(lps):
             one_launch(seed); seed += 1
+    drain()
     barrier()
     del launch_ms[:]
+    state["mc"] = 0
     t0 = time.perf_counter()
-    mc_total, res = 0, None
     for k in range(args.steps):
         for _ in range(lps):
-            res = one_launch(seed); seed += 1
-            mc_total += plan.total_steps
+            one_launch(seed); seed += 1
+    drain()
     barrier()
     dt = time.perf_counter() - t0
+    mc_total, res = state["mc"], state["res"]
+    gather_last()
     ranks_seen = 1
     if use_dist:
         dev = "cuda" if backend == "nccl" and not dry else "cpu"

@@ -455,6 +455,10 @@ struct mcsas_plan {
     uint64_t *d_timeline = nullptr;
     int32_t *h_done = nullptr;          // pinned + mapped: scan kernels count finished chains into it
     PipeArgs *d_pipeargs = nullptr;     // the argument block the tick kernels read (device copy)
+    PipeArgs *h_pipeargs = nullptr;     // ... and its pinned staging copy: the upload is a true asynchronous copy, so launch() of one plan does
+                                        // not wait for another plan's work queued on the same stream
+    hipStream_t sCopy = nullptr;        // fetch(): results come back on a non-blocking stream of their own (a blocking copy would
+                                        // wait for whatever else is queued on the null stream — another plan's launch)
     hipFunction_t plugin_fn = nullptr;  // wave kernel of a run-time model plug-in (this device's module), else null
     hipStream_t sP = nullptr, sS = nullptr;
     static constexpr int RING = 64;
@@ -507,6 +511,8 @@ extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     pl->pool.release();                 // every device array of the plan
     if (pl->h_stop) hipHostFree(pl->h_stop);
     if (pl->h_done) hipHostFree(pl->h_done);
+    if (pl->h_pipeargs) hipHostFree(pl->h_pipeargs);
+    if (pl->sCopy) hipStreamDestroy(pl->sCopy);
     for (int i = 0; i < mcsas_plan::RING; ++i) {
         if (pl->evP[i]) hipEventDestroy(pl->evP[i]);
         if (pl->evS[i]) hipEventDestroy(pl->evS[i]);
@@ -826,7 +832,9 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(tick, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     *pl->h_done = 0;
     pa.tick = 0;
-    HIPCHK(hipMemcpyAsync(pl->d_pipeargs, &pa, sizeof(PipeArgs), hipMemcpyHostToDevice, st));
+    if (!pl->h_pipeargs) HIPCHK(hipHostMalloc((void **)&pl->h_pipeargs, sizeof(PipeArgs), hipHostMallocDefault));
+    *pl->h_pipeargs = pa;                                // (the previous launch's upload has completed: fetch() or the caller waited for it)
+    HIPCHK(hipMemcpyAsync(pl->d_pipeargs, pl->h_pipeargs, sizeof(PipeArgs), hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(pl->ev0, st));
     {
         void *ka[] = {(void *)&pl->d_pipeargs};
@@ -921,14 +929,20 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
     DeviceGuard dev_guard;
     HIPCHK(hipSetDevice(pl->dev));
     // wait, forwarding the caller's stop word to the device-visible one (McSAS.stop, mcsas.py:357)
-    for (;;) {
+    while (pl->prob.stop) {                              // (no stop word: nothing to forward, plain wait below)
         hipError_t q = hipEventQuery(pl->ev1);
         if (q == hipSuccess) break;
         if (q != hipErrorNotReady) return fail(MCSAS_EHIP, "kernel failed: %s", hipGetErrorString(q));
-        if (pl->prob.stop && *pl->prob.stop) *pl->h_stop = 1;
+        if (*pl->prob.stop) *pl->h_stop = 1;
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     HIPCHK(hipEventSynchronize(pl->ev1));
+    if (!pl->sCopy) HIPCHK(hipStreamCreateWithFlags(&pl->sCopy, hipStreamNonBlocking));
+    // device -> host on the copy stream (the data is complete: ev1 has passed)
+    auto d2h = [&](void *dst, const void *src, size_t n) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, pl->sCopy);
+        return e != hipSuccess ? e : hipStreamSynchronize(pl->sCopy);
+    };
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, pl->ev0, pl->ev1));
     pl->last_ms = ms;
@@ -937,7 +951,7 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
         return fail(MCSAS_EHIP, "pipeline: %d of %zu chains finished within the %d ticks that were launched",
                     (int)*(volatile int32_t *)pl->h_done, R, pl->ticks_launched + 1);
     std::vector<ChainOut> ho(R);
-    HIPCHK(hipMemcpy(ho.data(), pl->d_out, sizeof(ChainOut) * R, hipMemcpyDeviceToHost));
+    HIPCHK(d2h(ho.data(), pl->d_out, sizeof(ChainOut) * R));
     int64_t steps = 0; int ovf = 0;
     for (size_t r = 0; r < R; ++r) { steps += ho[r].total_steps; ovf |= ho[r].stream_overflow; }
     pl->last_steps = steps;
@@ -954,7 +968,7 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
         if (pl->d_timeline) {
             const size_t nb = R + R * pl->pipe.g.prod_blocks_y;
             std::vector<uint64_t> tl(nb * 8 * PIPE_TL_WORDS);
-            HIPCHK(hipMemcpy(tl.data(), pl->d_timeline, tl.size() * 8, hipMemcpyDeviceToHost));
+            HIPCHK(d2h(tl.data(), pl->d_timeline, tl.size() * 8));
             uint64_t t0 = ~0ull;
             const size_t TW = PIPE_TL_WORDS;
             for (size_t i = 0; i < nb * 8; ++i) if (tl[i * TW] && tl[i * TW] < t0) t0 = tl[i * TW];
@@ -975,14 +989,14 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
     if (res) {
         if (res->contribs) {
             std::vector<double> hr(R * N * P);
-            HIPCHK(hipMemcpy(hr.data(), pl->d_rset, sizeof(double) * hr.size(), hipMemcpyDeviceToHost));
+            HIPCHK(d2h(hr.data(), pl->d_rset, sizeof(double) * hr.size()));
             for (size_t r = 0; r < R; ++r)
                 for (size_t n = 0; n < N; ++n)
                     for (size_t p = 0; p < P; ++p) res->contribs[(n * P + p) * R + r] = hr[(r * N + n) * P + p];
         }
         if (res->fit) {
             std::vector<double> hf(R * qpad);
-            HIPCHK(hipMemcpy(hf.data(), pl->d_fit, sizeof(double) * hf.size(), hipMemcpyDeviceToHost));
+            HIPCHK(d2h(hf.data(), pl->d_fit, sizeof(double) * hf.size()));
             for (size_t r = 0; r < R; ++r)
                 for (size_t k = 0; k < Q; ++k) res->fit[k * R + r] = hf[r * qpad + k];
         }
