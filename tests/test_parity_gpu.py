@@ -4,6 +4,8 @@ golden vectors.  Tolerances (fp64 path):
     ulps; the sphere's sin x - x cos x cancellation amplifies that to ~1e-12 at small q·R)
   * accept/reject decisions, iteration and move counts, parameter sets: exact
   * chi-squared, scaling: 1e-7 relative (north_star asks for 1e-5)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1117,3 +1119,21 @@ def test_run_series_replays_the_reference_series():
         for r in range(want.shape[0]):
             for c in range(1, want.shape[1], 2):
                 np.testing.assert_allclose(got[r, c], want[r, c], rtol=1e-4, atol=1e-9 * abs(want[r, c - 1]))
+
+
+def test_bench_workload_at_full_budget_equals_the_c_oracle_chain_by_chain():
+    """bench.py's headline workload exactly as it is timed — synthetic 512 q x 400 contributions x 50 repetitions x 20 000
+    steps, pipeline mode, Philox streams — against the plain-C oracle (oracle/c) run on the same counter-based streams: every
+    chain takes the same decisions over its full budget (move counts, final parameter sets: exact; chi-squared 1e-7)."""
+    from oracle import c_oracle
+    q, I, sig = _synthetic(512)
+    lo, hi = np.pi / q.max(), np.pi / q.min()
+    m, _ = make_models("sphere", [lo], [hi])
+    st = engine.Settings(n_contrib=400, n_reps=50, max_iter=20000, conv_crit=0.0, max_retries=0, seed=1000, exec_mode=engine.EXEC_PIPELINE)
+    res = engine.analyse(m.setup(), q, I, sig, st)
+    ref = c_oracle.analyse_sphere(q, I, sig, lo, hi, 400, 50, 20000, 0.0, seed=1000, threads=min(16, os.cpu_count() or 1))
+    assert (res.num_iter == 20000).all() and (ref.num_iter == 20000).all()
+    np.testing.assert_array_equal(res.num_moves, ref.num_moves)
+    np.testing.assert_allclose(res.contribs, ref.contribs, rtol=1e-12)
+    np.testing.assert_allclose(res.chisq, ref.chisq, rtol=1e-7)
+    assert 900 < res.num_moves.mean() < 1600            # (~6 % of the steps are accepted)
