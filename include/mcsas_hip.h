@@ -57,9 +57,10 @@ enum {
 /* exec_mode: how chains are mapped onto the chip.  Every mode replays the reference's trajectories decision for decision
  * (tests/test_parity_gpu.py); the modes sum the same terms in different orders, so two FREE-RUNNING chains with the same
  * seed can take different turns at a numerically tied step (replacing one negligible contribution by another moves chi²
- * by less than its rounding error).  A repetition's result is reproducible for the same mode — whatever the number of
- * repetitions or devices beside it for rows without an integral (the pipeline's window does not depend on the chain count);
- * for rows with an integral the pipeline's window does follow the chain count (csrc/chain_pipe.h: pipe_geometry).
+ * by less than its rounding error).  A repetition's result is reproducible for the same mode, whatever the number of
+ * repetitions or devices beside it: nothing a chain decides depends on how many chains share a launch (the pipeline's window
+ * is fixed for rows without an integral; for rows with an integral it follows the chain count, and the decisions are kept
+ * independent of it: csrc/chain_pipe.h, PipeGeom::resum_every).
  * q-points (the reference takes any data.count, mcsas.py:210): up to 1024 in every mode; 1025..16384 (un-binned data files,
  * nBin = 0) one workgroup per chain with the q-points split over its waves (csrc/chain_wide.h: MCSAS_EXEC_WORKGROUP, and
  * what MCSAS_EXEC_AUTO picks); up to 4096 MCSAS_EXEC_WAVE also runs; beyond 16384 MCSAS_EINVAL. */

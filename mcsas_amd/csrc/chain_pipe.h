@@ -74,6 +74,7 @@ struct PipeSnap {                 // what the producer needs to know about a cha
 struct PipeChain {                // per-chain scanner state, lives in HBM between ticks
     PipeSnap snap[2];
     double SC, SIC, SCC, A, b, chi2;
+    double X;                     // chi²·Q as the decisions carry it (PipeGeom::resum_every)
     int64_t num_iter, num_moves, total_steps;
     uint64_t draw_pos, t_start;
     int32_t attempts, converged, stopped, overflow, done, pad;
@@ -97,7 +98,9 @@ struct PipeGeom {
     int32_t overlap;              // producer variant (tuning): the Gram MFMAs of sub-window s are issued between the rows of s + 1, operands from HBM/L2
     int32_t gram_lds;             // producer: the sub-window's d rows are also kept in LDS and the Gram MFMAs read them from there
     int32_t drow_off;             // producer LDS: offset (doubles) of those rows, row stride qpad + PIPE_DROW_PAD
-    int32_t pad_g;
+    int32_t resum_every;          // 0: the running sums are re-derived from ft at the end of every window (the window is fixed: rows without an
+                                  // integral); n: at every n-th step of the attempt instead, and chi²·Q is carried across windows exactly —
+                                  // nothing a chain decides then depends on the window, which follows the chain count for rows with an integral
     uint64_t prod_lds, scan_lds;
 };
 
@@ -148,6 +151,7 @@ constexpr int PIPE_WAVES = PIPE_BLOCK / 64;
 constexpr int PIPE_GRAM_TILES_PER_ROUND = 2;
 constexpr int PIPE_DROW_PAD = 8;         // LDS d rows: stride qpad + 8 doubles, so that the 64 16-byte operands of one Gram load hit 64 different bank groups
 constexpr int PIPE_GRAM_NT_MAX = 3;          // overlapped producer: tiles per sub-window — W <= 32 (two 16-row groups: 3 tiles) or 24 packed (2)
+constexpr int PIPE_RESUM_STEPS = 64;        // rows with an integral: the running sums are re-derived from ft every 64 steps of an attempt (a multiple of the 8-step sub-window)
 constexpr int PIPE_MAX_ROW_DOUBLES = 32;   // scan block: doubles per lane held in row registers (rows per wave and sub-window x q per lane)   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
@@ -169,6 +173,9 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     // schemes cover W <= 32.
     const bool overlap = !heavy_rows && gram_global_req;
     auto pick_w = [&](int r) {
+        // rows with an integral: always 8 — which steps share a Gram block must not follow the rows per wave, and those
+        // follow the chain count (a repetition's result is to be the same beside 6 other chains as beside 49)
+        if (heavy_rows) return 8;
         int w = 8;
         for (int ws = 8; ws <= 8 * r && ws <= (overlap ? 32 : 64); ws += 8) {
             const int rps = ws / 8;
@@ -246,12 +253,13 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
     g->gram_off = 4 * qpad + tab_doubles;
+    g->resum_every = heavy_rows ? PIPE_RESUM_STEPS : 0;
     {
         // reduction buffer of the Gram tiles: [8 waves][tiles][256]; the overlapped producer keeps two of them (the block of
         // sub-window s is summed while the partial tiles of s + 1 are being parked)
         const size_t red = overlap ? (size_t)2 * PIPE_WAVES * PIPE_GRAM_NT_MAX * 256 : (size_t)PIPE_WAVES * PIPE_GRAM_TILES_PER_ROUND * 256;
         g->prod_lds = sizeof(double) * ((size_t)g->gram_off + 16 + red);    // 16 doubles: counters
-        g->overlap = overlap ? 1 : 0; g->pad_g = 0;
+        g->overlap = overlap ? 1 : 0;
         // Rows without an integral: the Gram phase is a third of the producer's tick; with the sub-window's d rows parked
         // in LDS on their way to HBM it is MFMA-bound instead of waiting for an L2 round trip per sub-window.
         g->gram_lds = 0; g->drow_off = 0;
@@ -1322,6 +1330,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
     int64_t num_iter = ch.num_iter, num_moves = ch.num_moves;
     int stopped = ch.stopped, overflow = 0;
     bool attempt_over = false;
+    double Xwin = 0.;                                           // chi²·Q at the end of this tick's window (PipeGeom::resum_every)
+    bool had_window = false;
 
     if (t < sn.t_init) {
         // nothing scheduled for this chain at this tick; just republish below
@@ -1413,7 +1423,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         for (int i = tid; i < kmax_all * 4; i += T) ssub[i] = scal[i];
         if (tid == 0) { lacc[Kb] = 0; sacc[0] = 0; }
         const double invSw = 1.0 / a.Sw, SIoSw = a.SI / a.Sw, Scen = a.SII - a.SI * a.SI / a.Sw;
-        double X = cur.chi2 * nqd;
+        const int resum = pa.g.resum_every;
+        double X = resum ? ch.X : cur.chi2 * nqd;
         bool touched = false, live = true;
         int num_acc_win = 0;
         if (wave == 0) {
@@ -1558,6 +1569,21 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 PIPE_LDS_BARRIER();                                        // B3: ft complete; sacc and the row buffer may be rewritten
                 load_row_pairs_lds<QPL>(lwft, lane, wftp);
             }
+            if (resum && wave == 0 && live && num_iter % resum == 0) {
+                // (rows with an integral) every `resum` steps of the attempt — wherever that falls in a window — the running
+                // sums are re-derived from ft so that the incremental updates cannot drift; ft is complete here (B3, or
+                // nothing was accepted in this sub-window)
+                double s1 = 0., s2 = 0., s3 = 0.;
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) {
+                    const double f = lft[lane + WAVE * j], wf = lwft[lane + WAVE * j];
+                    s1 += wf; s2 = fma(wf, f, s2); s3 = fma(gwI_[lane + WAVE * j], f, s3);
+                }
+                wave_sum3(s1, s2, s3);
+                SC = s1; SCC = s2; SIC = s3;
+                cur = solve_fit(a, SC, SCC, SIC);
+                X = cur.chi2 * nqd;
+            }
 #ifdef MCSAS_STAMPS
             MCSAS_STAMP(s5);
             ph[0] += s1 - s0; ph[1] += s2 - s1; ph[2] += s3 - s2; ph[3] += s4 - s3; ph[4] += s5 - s4; ph[5] += 1; ph[6] += nacc;
@@ -1597,7 +1623,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             }
         }
         if (wave == 0) {
-            if (touched) {
+            Xwin = X; had_window = true;
+            if (touched && !resum) {
                 // re-sum the fit sums from ft so the incremental updates cannot drift
                 double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
@@ -1673,6 +1700,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             // evaluating rows for it too (one word; a producer of this very launch that still reads 1 only does work nobody uses)
             if (done) glb(&pa.chains[rep].snap[(t + 1) & 1].alive)[0] = 0;
             ch.SC = SC; ch.SIC = SIC; ch.SCC = SCC; ch.A = cur.A; ch.b = cur.b; ch.chi2 = cur.chi2;
+            ch.X = had_window ? Xwin : cur.chi2 * nqd;            // (no window this tick: the attempt's initial fit)
             ch.num_iter = num_iter; ch.num_moves = num_moves; ch.total_steps = total_steps;
             ch.draw_pos = draw_pos; ch.attempts = attempts; ch.converged = converged; ch.stopped = stopped;
             if (overflow) atomicOr(&pa.chains[rep].overflow, 1);

@@ -1137,3 +1137,25 @@ def test_bench_workload_at_full_budget_equals_the_c_oracle_chain_by_chain():
     np.testing.assert_allclose(res.contribs, ref.contribs, rtol=1e-12)
     np.testing.assert_allclose(res.chisq, ref.chisq, rtol=1e-7)
     assert 900 < res.num_moves.mean() < 1600            # (~6 % of the steps are accepted)
+
+
+@pytest.mark.parametrize("tag", ["cyl_aspect", "kholodenko", "ellcs"])
+def test_rows_with_an_integral_give_the_same_chain_whatever_the_chain_count(tag):
+    """Pipeline mode, rows that cost an integral: the window (producer blocks per chain, rows per producer wave) follows the
+    number of chains in the launch — and nothing a chain decides may depend on it (8-step Gram blocks whatever the rows per
+    wave, running sums re-derived every 64 steps of the attempt wherever a window ends, chi²·Q carried across windows
+    exactly).  24 repetitions in one launch, in two launches of 12 and in launches of 5: bit for bit the same arrays — which is
+    what makes a device list (mcsas_problem.devices) reproduce one device for these models too."""
+    q, I, sig = _synthetic(128)
+    lo, hi = RANDOM_RANGES[tag]
+    kw = {"intDiv": 20.} if tag in ("cyl_aspect", "ellcs") else {}
+    m, _ = make_models(tag, lo, hi, **kw)
+    st = engine.Settings(n_contrib=400, n_reps=24, max_iter=900, conv_crit=1e-9, max_retries=0, seed=21, exec_mode=engine.EXEC_PIPELINE)
+    one = engine.analyse(m.setup(), q, I, sig, st)
+    windows = {engine.Plan(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "n_reps": r})).info["window"] for r in (24, 12, 5)}
+    assert len(windows) > 1                                   # the geometries really differ
+    assert one.num_moves.min() > 0 and len(set(one.num_moves.tolist())) > 3
+    for devs in ((0, 0), (0,) * 5):
+        many = engine.analyse(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "devices": devs}))
+        for name in ("contribs", "fit", "chisq", "scaling", "background", "num_iter", "num_moves"):
+            np.testing.assert_array_equal(getattr(many, name), getattr(one, name), err_msg="%s with %d blocks" % (name, len(devs)))
