@@ -261,8 +261,10 @@ int mcsas_hip_rebin(int32_t n, const double *x, const double *f, const double *f
  *     __device__ double mcsas_plugin_surface(const double *p);                 // .surface()
  * (csrc/fastmath.h and device_util.h are in scope, namespace mcsas.)  The text is compiled with hiprtc for gfx950 against
  * the library's own kernel headers, which it carries inside; no GPU is needed for that.  *model_id (>= MCSAS_MODEL_PLUGIN0)
- * is then valid as mcsas_problem.model_id in every entry point; chains of a plug-in model run one wavefront per chain
- * (exec_mode MCSAS_EXEC_AUTO or MCSAS_EXEC_WAVE, nq <= 1024; no beam-profile smearing).  The same text registered twice
+ * is then valid as mcsas_problem.model_id in every entry point and every execution mode (the chain kernel of the mode is
+ * compiled for the plug-in on first use: 0.5 - 15 s once per q-slot count), nq <= 1024, no beam-profile smearing.  A form
+ * factor that loops over orientations / a contour should say `#define MCSAS_PLUGIN_ROW_CLASS 1` (csrc/plugin_model.h: how
+ * the pipeline spreads such rows over the chip; results do not depend on it).  The same text registered twice
  * gives the same id.  MCSAS_EINVAL + mcsas_hip_plugin_log() (compiler output, calling thread) if it does not compile. */
 int         mcsas_hip_plugin_compile(const char *source, int32_t *model_id);
 const char *mcsas_hip_plugin_log(void);

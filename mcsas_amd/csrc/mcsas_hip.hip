@@ -174,6 +174,7 @@ __global__ __launch_bounds__(64) void rebin_kernel(int n, const double *x, const
 
 struct Plugin {
     std::string source;
+    int row_class = 0;                  // `#define MCSAS_PLUGIN_ROW_CLASS n` in the text (plugin_model.h)
     std::mutex mu;
     struct Program { std::vector<char> code; std::map<std::string, std::string> lowered; };
     std::map<std::string, Program> programs;                                  // by program key ("small", "wave 8 1", ...)
@@ -196,9 +197,9 @@ static int plugin_compile_program(const std::string &source, const std::vector<s
     std::string tu =
         "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
         "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"
-        "#include \"chain_wave.h\"\n#include \"small_kernels.h\"\n#include \"plugin_model.h\"\n#line 1 \"plugin\"\n";
+        "#include \"chain_common.h\"\n#line 1 \"plugin\"\n";
     tu += source;
-    tu += "\n";
+    tu += "\n#include \"plugin_model.h\"\n#include \"chain_wave.h\"\n#include \"chain_wg.h\"\n#include \"chain_pipe.h\"\n#include \"small_kernels.h\"\n";
     hiprtcProgram prog = nullptr;
     hiprtcResult r = hiprtcCreateProgram(&prog, tu.c_str(), "mcsas_plugin.hip", mcsas_embedded_count, const_cast<const char **>(mcsas_embedded_texts),
                                          const_cast<const char **>(mcsas_embedded_names));
@@ -258,6 +259,18 @@ static int plugin_small_function(int model_id, int which, hipFunction_t *fn) {
     const std::vector<std::string> exprs(PLUGIN_SMALL_EXPRS, PLUGIN_SMALL_EXPRS + 3);
     return plugin_function(model_id, "small", exprs, exprs[which], fn);
 }
+static int plugin_wg_function(int model_id, int qpl, hipFunction_t *fn) {
+    char e[128], k[32];
+    snprintf(e, sizeof e, "mcsas::chain_wg_kernel<MCSAS_MODEL_PLUGIN, %d>", qpl);
+    snprintf(k, sizeof k, "wg %d", qpl);
+    return plugin_function(model_id, k, {e}, e, fn);
+}
+static int plugin_pipe_function(int model_id, int qpl, hipFunction_t *fn) {
+    char e[128], k[32];
+    snprintf(e, sizeof e, "mcsas::pipe_tick_kernel<MCSAS_MODEL_PLUGIN, %d>", qpl);
+    snprintf(k, sizeof k, "pipe %d", qpl);
+    return plugin_function(model_id, k, {e}, e, fn);
+}
 static int plugin_wave_function(int model_id, int qpl, bool cache, hipFunction_t *fn) {
     char e[128], k[32];
     snprintf(e, sizeof e, "mcsas::chain_wave_kernel<MCSAS_MODEL_PLUGIN, %d, %s>", qpl, cache ? "true" : "false");
@@ -288,6 +301,12 @@ extern "C" int mcsas_hip_plugin_compile(const char *source, int32_t *model_id) {
     // the small kernels are compiled here, so that a plug-in that does not compile is refused before anything uses it
     auto pg = std::make_unique<Plugin>();
     pg->source = source;
+    {   // the row class the text declares (the kernels see the macro; the host needs the number for the pipeline's geometry)
+        const char *key = "MCSAS_PLUGIN_ROW_CLASS";
+        size_t at = pg->source.find(std::string("#define ") + key);
+        if (at != std::string::npos) pg->row_class = atoi(pg->source.c_str() + at + 8 + strlen(key));
+        if (pg->row_class < 0 || pg->row_class > 1) return fail(MCSAS_EINVAL, "MCSAS_PLUGIN_ROW_CLASS %d (0 or 1)", pg->row_class);
+    }
     Plugin::Program prg;
     const std::vector<std::string> exprs(PLUGIN_SMALL_EXPRS, PLUGIN_SMALL_EXPRS + 3);
     int rc = plugin_compile_program(pg->source, exprs, &prg);
@@ -304,13 +323,14 @@ extern "C" const char *mcsas_hip_plugin_log(void) { return g_plugin_log.c_str();
 // ------------------------------------------------------------------------------ host helpers
 // what the host needs to know about a model, read off its Contrib<M> (models.h) — no per-model code below this table
 struct ModelTraits { int int_div_param, rowtab, row_class; bool can_smear; int (*table_doubles)(int); };
-static const ModelTraits &model_traits(int model_id) {
+static ModelTraits model_traits(int model_id) {
 #define TRAITS_OF(m) {Contrib<m>::INT_DIV_PARAM, Contrib<m>::ROWTAB, Contrib<m>::ROW_CLASS, Contrib<m>::CAN_SMEAR, &Contrib<m>::table_doubles},
     static const ModelTraits builtin[] = {MCSAS_FOR_MODELS(TRAITS_OF)};
 #undef TRAITS_OF
-    static const ModelTraits plugin = {-1, 0, 0, false, [](int) { return 0; }};      // plugin_model.h
     static_assert(sizeof builtin / sizeof builtin[0] == MCSAS_MODEL_COUNT, "model_list.h and include/mcsas_hip.h disagree");
-    return (model_id >= 0 && model_id < MCSAS_MODEL_COUNT) ? builtin[model_id] : plugin;
+    if (model_id >= 0 && model_id < MCSAS_MODEL_COUNT) return builtin[model_id];
+    const Plugin *pg = plugin_of(model_id);                                           // plugin_model.h
+    return ModelTraits{-1, 0, pg ? pg->row_class : 0, false, [](int) { return 0; }};
 }
 static int model_int_div(const mcsas_problem *p) {
     const int i = model_traits(p->model_id).int_div_param;
@@ -459,7 +479,7 @@ struct mcsas_plan {
                                         // not wait for another plan's work queued on the same stream
     hipStream_t sCopy = nullptr;        // fetch(): results come back on a non-blocking stream of their own (a blocking copy would
                                         // wait for whatever else is queued on the null stream — another plan's launch)
-    hipFunction_t plugin_fn = nullptr;  // wave kernel of a run-time model plug-in (this device's module), else null
+    hipFunction_t plugin_fn = nullptr;  // the chain kernel of a run-time model plug-in for this plan's mode and q count (this device's module), else null
     hipStream_t sP = nullptr, sS = nullptr;
     static constexpr int RING = 64;
     hipEvent_t evP[RING] = {}, evS[RING] = {};
@@ -632,13 +652,9 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     int mode = p->exec_mode;
     int waves = p->waves_per_chain;
     const bool plugin = is_plugin_model(p->model_id);
-    if (plugin) {
-        // run-time model plug-ins are compiled into the wave-per-chain kernel only (plugin_model.h)
-        if ((mode != MCSAS_EXEC_AUTO && mode != MCSAS_EXEC_WAVE) || waves > 1 || wide_q) {
-            mcsas_hip_plan_destroy(pl);
-            return fail(MCSAS_EINVAL, "model plug-ins run one wavefront per chain, nq <= 1024 (exec_mode %d, waves_per_chain %d, nq %d asked)", p->exec_mode, waves, p->nq);
-        }
-        mode = MCSAS_EXEC_WAVE; waves = 1;
+    if (plugin && wide_q) {
+        mcsas_hip_plan_destroy(pl);
+        return fail(MCSAS_EINVAL, "model plug-ins: up to 1024 q-points (nq %d asked)", p->nq);
     }
     if (mode == MCSAS_EXEC_AUTO) {
         if (waves == 1) mode = MCSAS_EXEC_WAVE;
@@ -772,7 +788,15 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         if (!wide_kernel_for(p->model_id, qpl)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no q-split kernel for model %d qpl %d", p->model_id, qpl); }
     } else if (mode == MCSAS_EXEC_WORKGROUP) {
         pl->lds_bytes = pl->wg.lds_bytes;
+        if (plugin) {
+            rc = plugin_wg_function(p->model_id, qpl, &pl->plugin_fn);
+            if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
+        }
     } else {
+        if (plugin) {
+            rc = plugin_pipe_function(p->model_id, qpl, &pl->plugin_fn);
+            if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
+        }
         PipeArgs &pa = pl->pipe;
         const size_t Kb = pa.g.kb;
         PCHK(pl->pool.get(&pl->d_chains, sizeof(PipeChain) * R));
@@ -826,10 +850,10 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     pa.c = pl->args;                                     // picks up reseed()
     pa.c.cache_rows = pl->args.cache_rows;
     const int R = pl->prob.n_reps, Kb = pa.g.kb;
-    void *tick = pipe_tick_kernel_for(pl->prob.model_id, pl->qpl), *reset = mcsas_pipe_reset_kernel();
-    if (!tick) return fail(MCSAS_EINVAL, "no pipeline kernel for model %d qpl %d", pl->prob.model_id, pl->qpl);
+    void *tick = pl->plugin_fn ? nullptr : pipe_tick_kernel_for(pl->prob.model_id, pl->qpl), *reset = mcsas_pipe_reset_kernel();
+    if (!tick && !pl->plugin_fn) return fail(MCSAS_EINVAL, "no pipeline kernel for model %d qpl %d", pl->prob.model_id, pl->qpl);
     const size_t lds = std::max(pa.g.prod_lds, pa.g.scan_lds);
-    if (lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(tick, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (tick && lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(tick, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     *pl->h_done = 0;
     pa.tick = 0;
     if (!pl->h_pipeargs) HIPCHK(hipHostMalloc((void **)&pl->h_pipeargs, sizeof(PipeArgs), hipHostMallocDefault));
@@ -863,7 +887,8 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
         }
         int32_t tk = (int32_t)t, stop_now = (pl->prob.stop && *(volatile int32_t *)pl->prob.stop) ? 1 : 0;
         void *ka[] = {(void *)&pl->d_pipeargs, (void *)&tk, (void *)&stop_now, (void *)&hot};
-        HIPCHK(hipLaunchKernel(tick, grid, dim3(PIPE_BLOCK), ka, lds, st));
+        if (tick) HIPCHK(hipLaunchKernel(tick, grid, dim3(PIPE_BLOCK), ka, lds, st));
+        else HIPCHK(hipModuleLaunchKernel(pl->plugin_fn, grid.x, 1, 1, PIPE_BLOCK, 1, 1, (unsigned)lds, st, ka, nullptr));
         if (t >= 0 && (t % 16) == 0) HIPCHK(hipEventRecord(pl->evS[(t / 16) % mcsas_plan::RING], st));
     }
     pl->ticks_launched = (int)t;
@@ -886,9 +911,12 @@ extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
     void *kargs[] = {(void *)&pl->args};
     void *fn;
     dim3 grid(pl->prob.n_reps), block;
-    if (pl->plugin_fn) {
+    if (pl->plugin_fn) {                                  // a run-time model plug-in: the same arguments, through its code-object module
+        void *kargs2[] = {(void *)&pl->args, (void *)&pl->wg};
+        const bool wgm = pl->mode == MCSAS_EXEC_WORKGROUP;
         HIPCHK(hipEventRecord(pl->ev0, st));
-        HIPCHK(hipModuleLaunchKernel(pl->plugin_fn, grid.x, 1, 1, WAVE, 1, 1, (unsigned)pl->lds_bytes, st, kargs, nullptr));
+        HIPCHK(hipModuleLaunchKernel(pl->plugin_fn, grid.x, 1, 1, wgm ? WAVE * pl->waves : WAVE, 1, 1, (unsigned)pl->lds_bytes, st,
+                                     wgm ? kargs2 : kargs, nullptr));
         HIPCHK(hipEventRecord(pl->ev1, st));
         pl->stream = st; pl->launched = true;
         return MCSAS_OK;

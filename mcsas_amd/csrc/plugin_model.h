@@ -11,9 +11,17 @@
 //     __device__ double mcsas_plugin_surface(const double *p);                 // .surface()
 //
 // Everything in fastmath.h / device_util.h is available to it (sincos_fast, div_fast, j1_fast, ...).  This header is compiled
-// only by hiprtc, in a translation unit assembled by the library: chain_wave.h, small_kernels.h, this file, the plug-in text.
+// only by hiprtc, in a translation unit assembled by the library: chain_common.h, the plug-in text, this file, then the kernel
+// templates (chain_wave.h, chain_wg.h, chain_pipe.h, small_kernels.h) of which the requested ones are instantiated.
 #pragma once
 #include "models.h"
+
+// What a row of this model costs (models.h, ROW_CLASS), as the pipeline should treat it: 0 = a few hundred instructions per q
+// point (the default), 1 = an integral per q point (the form factor loops over orientations / a contour).  The plug-in text
+// may say `#define MCSAS_PLUGIN_ROW_CLASS 1`; results do not depend on it, only how the rows are spread over the chip.
+#ifndef MCSAS_PLUGIN_ROW_CLASS
+#define MCSAS_PLUGIN_ROW_CLASS 0
+#endif
 
 __device__ double mcsas_plugin_formfactor(double q, const double *p);
 __device__ double mcsas_plugin_volume(const double *p);
@@ -23,7 +31,7 @@ __device__ double mcsas_plugin_surface(const double *p);
 namespace mcsas {
 
 template <> struct Contrib<MCSAS_MODEL_PLUGIN> {
-    static constexpr int ROWTAB = 0, INT_DIV_PARAM = -1, ROW_CLASS = 0;
+    static constexpr int ROWTAB = 0, INT_DIV_PARAM = -1, ROW_CLASS = MCSAS_PLUGIN_ROW_CLASS;
     static constexpr bool CAN_SMEAR = false;
     double p[MCSAS_MAX_PARAMS];
     double v, w, s;

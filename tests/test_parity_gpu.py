@@ -989,36 +989,39 @@ def test_pipeline_geometry_follows_the_chain_count():
 # ------------------------------------------------------------------------------ run-time model plug-ins
 @pytest.mark.parametrize("tag,name", [("gausschain", "g4_gausschain_q40.npz"), ("sphcs", "g4_sphcs_q40.npz")])
 def test_plugin_model_replays_the_reference_and_equals_its_built_in_twin(tag, name):
-    """A model that reaches the library as HIP source text (mcsas_hip_plugin_compile) runs the same wave-per-chain kernel as the
-    built-in ones: written operation for operation like its built-in twin it replays the reference's trajectory and is
-    bit-identical to the twin — chain results, ScatteringModel.calc and the histogram preparation alike."""
+    """A model that reaches the library as HIP source text (mcsas_hip_plugin_compile) runs the same kernels as the built-in
+    ones, in every execution mode: written operation for operation like its built-in twin it replays the reference's trajectory
+    and is bit-identical to the twin — chain results, ScatteringModel.calc and the histogram preparation alike."""
     from helpers import plugin_twin
     g, m, spec, st, ost = traj_setup(name)
     q, I, sig = g["data_q"], g["data_I"], g["data_sigma"]
-    st.exec_mode, st.waves_per_chain = engine.EXEC_WAVE, 1
-    ref = engine.analyse(m.setup(FakeData(q)), q, I, sig, st, replay=g["stream"][None, :])
+    modes = [(engine.EXEC_WAVE, 1, 1), (engine.EXEC_WAVE, 1, 0), (engine.EXEC_WORKGROUP, 8, 1), (engine.EXEC_PIPELINE, 0, 1)]
+    refs = []
+    for mode, waves, cache in modes:
+        st.exec_mode, st.waves_per_chain, st.cache_intensities = mode, waves, cache
+        refs.append(engine.analyse(m.setup(FakeData(q)), q, I, sig, st, replay=g["stream"][None, :]))
+    ref = refs[0]
     pset = np.array(ref.contribs[:, :, 0])
     calc_ref = engine.model_calc(m.setup(), q, pset, st.comp_exp, want_rows=True)
     prep_ref = engine.histogram_prep(m.setup(), q, I, sig, ref.contribs, st.comp_exp, st.find_background, st.positive_background)
     plugin_twin(m, tag)
     setup = m.setup(FakeData(q))
     assert setup.model_id >= engine.MODEL_PLUGIN0
-    for cache in (1, 0):
-        st.cache_intensities = cache
+    for (mode, waves, cache), twin in zip(modes, refs):
+        st.exec_mode, st.waves_per_chain, st.cache_intensities = mode, waves, cache
         res = engine.analyse(setup, q, I, sig, st, replay=g["stream"][None, :])
         assert res.num_iter[0] == int(g["res_num_iter"]) and res.num_moves[0] == int(g["res_num_moves"])
         np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
         np.testing.assert_allclose(res.chisq[0], float(g["res_conval"]), rtol=1e-7)
-        if cache:
-            assert np.array_equal(res.contribs, ref.contribs) and np.array_equal(res.fit, ref.fit) and res.chisq[0] == ref.chisq[0]
+        assert np.array_equal(res.contribs, twin.contribs) and np.array_equal(res.fit, twin.fit) and res.chisq[0] == twin.chisq[0], (mode, waves, cache)
     for a, b in zip(engine.model_calc(setup, q, pset, st.comp_exp, want_rows=True), calc_ref):
         assert np.array_equal(a, b)
     for a, b in zip(engine.histogram_prep(setup, q, I, sig, ref.contribs, st.comp_exp, st.find_background, st.positive_background), prep_ref):
         assert np.array_equal(a, b)
-    # the other execution modes have no plug-in kernels: refused, not silently replaced
-    st.exec_mode, st.waves_per_chain = engine.EXEC_PIPELINE, 0
+    # more than 1024 q-points have no plug-in kernels: refused, not silently replaced
+    qw, Iw, sw = _synthetic(1500)
     with pytest.raises(mcsas_amd._lib.McSASHipError) as e:
-        engine.analyse(setup, q, I, sig, st, replay=g["stream"][None, :])
+        engine.analyse(setup, qw, Iw, sw, engine.Settings(n_contrib=20, n_reps=1, max_iter=10, conv_crit=0.0, max_retries=0))
     assert e.value.code == -1
 
 
@@ -1045,6 +1048,7 @@ def test_plugin_model_through_the_mcsas_front_end():
         algo.data = mcsas_amd.SASData(q, I, sig)
         algo.calc()
         out.append(algo.result[0])
+        assert engine.Plan(m.setup(), q, I, sig, algo._settings(40, 4)).info["exec_mode"] == "pipeline"   # what auto picks for 4 chains
     a, b = out
     assert np.array_equal(a["contribs"], b["contribs"]) and np.array_equal(a["fitMeasValMean"], b["fitMeasValMean"])
     assert np.array_equal(a["scalingFactors"], b["scalingFactors"])
