@@ -175,6 +175,7 @@ __global__ __launch_bounds__(64) void rebin_kernel(int n, const double *x, const
 struct Plugin {
     std::string source;
     int row_class = 0;                  // `#define MCSAS_PLUGIN_ROW_CLASS n` in the text (plugin_model.h)
+    bool can_smear = false;             // `#define MCSAS_PLUGIN_CAN_SMEAR 1`
     std::mutex mu;
     struct Program { std::vector<char> code; std::map<std::string, std::string> lowered; };
     std::map<std::string, Program> programs;                                  // by program key ("small", "wave 8 1", ...)
@@ -306,6 +307,9 @@ extern "C" int mcsas_hip_plugin_compile(const char *source, int32_t *model_id) {
         size_t at = pg->source.find(std::string("#define ") + key);
         if (at != std::string::npos) pg->row_class = atoi(pg->source.c_str() + at + 8 + strlen(key));
         if (pg->row_class < 0 || pg->row_class > 1) return fail(MCSAS_EINVAL, "MCSAS_PLUGIN_ROW_CLASS %d (0 or 1)", pg->row_class);
+        const char *key2 = "MCSAS_PLUGIN_CAN_SMEAR";
+        at = pg->source.find(std::string("#define ") + key2);
+        if (at != std::string::npos) pg->can_smear = atoi(pg->source.c_str() + at + 8 + strlen(key2)) != 0;
     }
     Plugin::Program prg;
     const std::vector<std::string> exprs(PLUGIN_SMALL_EXPRS, PLUGIN_SMALL_EXPRS + 3);
@@ -330,7 +334,7 @@ static ModelTraits model_traits(int model_id) {
     static_assert(sizeof builtin / sizeof builtin[0] == MCSAS_MODEL_COUNT, "model_list.h and include/mcsas_hip.h disagree");
     if (model_id >= 0 && model_id < MCSAS_MODEL_COUNT) return builtin[model_id];
     const Plugin *pg = plugin_of(model_id);                                           // plugin_model.h
-    return ModelTraits{-1, 0, pg ? pg->row_class : 0, false, [](int) { return 0; }};
+    return ModelTraits{-1, 0, pg ? pg->row_class : 0, pg ? pg->can_smear : false, [](int) { return 0; }};
 }
 static int model_int_div(const mcsas_problem *p) {
     const int i = model_traits(p->model_id).int_div_param;

@@ -22,6 +22,11 @@
 #ifndef MCSAS_PLUGIN_ROW_CLASS
 #define MCSAS_PLUGIN_ROW_CLASS 0
 #endif
+// The reference's canSmear flag of the model class (sasmodel.py:56-60): `#define MCSAS_PLUGIN_CAN_SMEAR 1` makes every
+// intensity of this model 2 trapz(F(locs)^2 w weights, x = qOffset) when the data set's smearing is configured.
+#ifndef MCSAS_PLUGIN_CAN_SMEAR
+#define MCSAS_PLUGIN_CAN_SMEAR 0
+#endif
 
 __device__ double mcsas_plugin_formfactor(double q, const double *p);
 __device__ double mcsas_plugin_volume(const double *p);
@@ -32,7 +37,7 @@ namespace mcsas {
 
 template <> struct Contrib<MCSAS_MODEL_PLUGIN> {
     static constexpr int ROWTAB = 0, INT_DIV_PARAM = -1, ROW_CLASS = MCSAS_PLUGIN_ROW_CLASS;
-    static constexpr bool CAN_SMEAR = false;
+    static constexpr bool CAN_SMEAR = MCSAS_PLUGIN_CAN_SMEAR != 0;
     double p[MCSAS_MAX_PARAMS];
     double v, w, s;
     static __host__ __device__ __forceinline__ int table_doubles(int) { return 0; }

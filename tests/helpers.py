@@ -166,6 +166,21 @@ __device__ double mcsas_plugin_formfactor(double q, const double *p) {
 }
 
 
+PLUGIN_SOURCES["sphere"] = r"""
+// models/sphere.py:37-63; p = (radius, sld); canSmear = True
+#define MCSAS_PLUGIN_CAN_SMEAR 1
+__device__ double mcsas_plugin_volume(const double *p) { return (mcsas::PI * 4. / 3.) * (p[0] * p[0] * p[0]); }
+__device__ double mcsas_plugin_absvolume(const double *p) { return mcsas_plugin_volume(p) * (p[1] * p[1]); }
+__device__ double mcsas_plugin_surface(const double *p) { return 4. * mcsas::PI * p[0] * p[0]; }
+__device__ double mcsas_plugin_formfactor(double q, const double *p) {
+    const double x = q * p[0];
+    double sn, cs;
+    mcsas::sincos_fast(x, &sn, &cs);
+    return 3. * (sn - x * cs) / (x * x * x);
+}
+"""
+
+
 def plugin_twin(model, tag):
     """The same configured model instance, but as a user's own class: no built-in kernel id, its form factor as HIP text."""
     model.__class__ = type(type(model).__name__ + "AsPlugin", (type(model),), {"model_id": None, "hipSource": PLUGIN_SOURCES[tag]})

@@ -1163,3 +1163,33 @@ def test_rows_with_an_integral_give_the_same_chain_whatever_the_chain_count(tag)
         many = engine.analyse(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "devices": devs}))
         for name in ("contribs", "fit", "chisq", "scaling", "background", "num_iter", "num_moves"):
             np.testing.assert_array_equal(getattr(many, name), getattr(one, name), err_msg="%s with %d blocks" % (name, len(devs)))
+
+
+def test_plugin_model_with_can_smear_matches_the_reference_smeared_intensities():
+    """A plug-in that declares canSmear (`#define MCSAS_PLUGIN_CAN_SMEAR 1`, plus `canSmear = True` on the model class) is
+    smeared like the built-in models: the reference's smeared sphere intensities (fixture g7, slit and pinhole trapezoid,
+    Gaussian) through a sphere written as plug-in text, and a short smeared chain equal in wave and pipeline mode."""
+    from helpers import plugin_twin
+    g = load("g7_smearing.npz")
+    for tag, kind, two_d in SMEAR_CASES:
+        pre = tag + "_"
+        q = g[pre + "q"]
+        widths = {k: float(g[pre + k]) for k in ("umbra", "penumbra", "variance") if pre + k in g}
+        d, args = product_smearing(kind, two_d, int(g[pre + "n_steps"]), q, **widths)
+        m, _ = make_models("sphere", [1e-10], [1e-6])
+        plugin_twin(m, "sphere")
+        assert m.canSmear and m.setup().model_id >= engine.MODEL_PLUGIN0
+        cum, v, w, s, rows = engine.model_calc(m.setup(), q, g[pre + "sphere_radii"][:, None], 0.6666666, want_rows=True, smear=d.smearArgs(m))
+        np.testing.assert_allclose(rows, g[pre + "sphere_it"], rtol=1e-9)
+    q, I, sig = _synthetic(100)
+    d, _ = product_smearing("trapezoid", False, 15, q, I, sig, umbra=2e-3 * q.max(), penumbra=4e-3 * q.max())
+    m, _ = make_models("sphere", [np.pi / q.max()], [np.pi / q.min()])
+    plugin_twin(m, "sphere")
+    out = []
+    for mode in (engine.EXEC_WAVE, engine.EXEC_PIPELINE):
+        st = engine.Settings(n_contrib=40, n_reps=3, max_iter=300, conv_crit=1e-9, max_retries=0, seed=4, exec_mode=mode)
+        out.append(engine.analyse(m.setup(), q, I, sig, st, smear=d.smearArgs(m)))
+    assert out[0].num_moves.sum() > 0 and np.array_equal(out[0].num_moves, out[1].num_moves)
+    np.testing.assert_array_equal(out[0].contribs, out[1].contribs)
+    unsmeared = engine.analyse(m.setup(), q, I, sig, engine.Settings(n_contrib=40, n_reps=3, max_iter=300, conv_crit=1e-9, max_retries=0, seed=4, exec_mode=engine.EXEC_WAVE))
+    assert not np.array_equal(unsmeared.contribs, out[0].contribs)
