@@ -117,7 +117,8 @@ struct PipeArgs {
     int32_t *row_valid;           // [R][N]  lazy_rows: 1 = the contribution's cached row is current
     double *pval;                 // [R][2][kb][MAX_ACTIVE]
     int32_t *povf;                // [R][2][kb]
-    int32_t *n_done;              // host-mapped: number of finished chains
+    int32_t *n_done;              // host-mapped: set to the number of chains when the last one has finished
+    int32_t *n_done_dev;          // device counter behind it (one system-scope atomic per chain cost the last tick 30 us)
     int32_t tick, pad;            // unused: the tick travels as its own kernel argument
     uint64_t *timeline;           // stamps build: [blocks][8 waves][2] wall clock (10 ns) at wave start / end of tick `timeline_tick`
     int32_t timeline_tick, pad1;
@@ -1337,13 +1338,26 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         // nothing scheduled for this chain at this tick; just republish below
     } else if (t == sn.t_init) {
         // ---- model.calc over the initial set: rows summed in contribution order (scatteringmodel.py:90-101)
+        // One q per thread, the N rows in batches of 16 loads (one wave walking the rows one dependent load at a time took
+        // ~100 us at N = 400: a fortieth of a 20 000-step launch); every q is summed in contribution order, as before.
+        for (int i = tid; i < qpad; i += T) {
+            double f = 0.;
+            int n = 0;
+            for (; n + 16 <= N; n += 16) {
+                double v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = cache[(size_t)(n + k) * qpad + i];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) f += v[k];
+            }
+            for (; n < N; ++n) f += cache[(size_t)n * qpad + i];
+            lft[i] = f;
+        }
+        PIPE_LDS_BARRIER();                                    // (t == t_init for every thread of the block)
         if (wave == 0) {
             double ft[QPL];
 #pragma unroll
-            for (int j = 0; j < QPL; ++j) ft[j] = 0.;
-            for (int n = 0; n < N; ++n)
-#pragma unroll
-                for (int j = 0; j < QPL; ++j) ft[j] += cache[(size_t)n * qpad + lane + WAVE * j];
+            for (int j = 0; j < QPL; ++j) ft[j] = lft[lane + WAVE * j];
             double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
@@ -1716,7 +1730,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 for (int i = 0; i < 20; ++i) o.dbg[i] = ch.dbg[i];
 #endif
                 a.out[rep] = o;
-                __hip_atomic_fetch_add(pa.n_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (__hip_atomic_fetch_add(pa.n_done_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == a.n_reps)
+                    __hip_atomic_store(pa.n_done, a.n_reps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

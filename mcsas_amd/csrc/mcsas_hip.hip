@@ -477,7 +477,8 @@ struct mcsas_plan {
     double *d_ft = nullptr, *d_wft = nullptr, *d_dwin = nullptr, *d_gwin = nullptr, *d_scal = nullptr, *d_pval = nullptr;
     int32_t *d_slot_of = nullptr, *d_stage = nullptr, *d_povf = nullptr, *d_row_valid = nullptr;
     uint64_t *d_timeline = nullptr;
-    int32_t *h_done = nullptr;          // pinned + mapped: scan kernels count finished chains into it
+    int32_t *h_done = nullptr;          // pinned + mapped: the scan block of the last chain to finish writes the chain count into it
+    int32_t *d_done_dev = nullptr;      // the device counter behind it
     PipeArgs *d_pipeargs = nullptr;     // the argument block the tick kernels read (device copy)
     PipeArgs *h_pipeargs = nullptr;     // ... and its pinned staging copy: the upload is a true asynchronous copy, so launch() of one plan does
                                         // not wait for another plan's work queued on the same stream
@@ -824,7 +825,8 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         pa.c = a;
         pa.chains = pl->d_chains; pa.ft = pl->d_ft; pa.wft = pl->d_wft; pa.slot_of = pl->d_slot_of;
         pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.gwin = pl->d_gwin; pa.scal = pl->d_scal; pa.row_valid = pl->d_row_valid; pa.pval = pl->d_pval;
-        pa.povf = pl->d_povf; pa.n_done = d_done; pa.tick = 0;
+        PCHK(pl->pool.get(&pl->d_done_dev, sizeof(int32_t)));
+        pa.povf = pl->d_povf; pa.n_done = d_done; pa.n_done_dev = pl->d_done_dev; pa.tick = 0;
         pa.timeline = nullptr; pa.timeline_tick = -100;
 #ifdef MCSAS_STAMPS
         if (const char *e = getenv("MCSAS_TIMELINE_TICK")) {
@@ -859,6 +861,7 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     const size_t lds = std::max(pa.g.prod_lds, pa.g.scan_lds);
     if (tick && lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(tick, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     *pl->h_done = 0;
+    HIPCHK(hipMemsetAsync(pl->d_done_dev, 0, sizeof(int32_t), st));
     pa.tick = 0;
     if (!pl->h_pipeargs) HIPCHK(hipHostMalloc((void **)&pl->h_pipeargs, sizeof(PipeArgs), hipHostMallocDefault));
     *pl->h_pipeargs = pa;                                // (the previous launch's upload has completed: fetch() or the caller waited for it)
@@ -873,7 +876,11 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     const long long TICK_CAP = 2000000000LL;
     const long long win_per_attempt = (long long)(pl->prob.max_iter / Kb) + 4;
     const long long attempts = (long long)pl->prob.max_retries + 1;
-    const long long max_ticks = (win_per_attempt >= TICK_CAP / attempts) ? TICK_CAP : std::min(attempts * win_per_attempt + 4, TICK_CAP);
+    // one attempt: its last window (index ceil(max_iter / Kb) - 1) is scanned at tick ceil(max_iter / Kb), exactly; with
+    // retries the schedule depends on when attempts end, so the bound is generous and the host leaves when all chains are done
+    const long long one_attempt = std::min((long long)((pl->prob.max_iter + Kb - 1) / Kb) + 1, TICK_CAP);
+    const long long max_ticks = attempts == 1 ? one_attempt
+                              : ((win_per_attempt >= TICK_CAP / attempts) ? TICK_CAP : std::min(attempts * win_per_attempt + 4, TICK_CAP));
     // scan blocks + producer blocks (chain-major; 8 XCD classes of ceil(R/8) chains each with diagnostic bit 128)
     const dim3 grid((MCSAS_TUNE_BITS(pl->args) & 128) ? R + 8 * ((R + 7) / 8) * pa.g.prod_blocks_y : R + R * pa.g.prod_blocks_y);
     PipeHot hot{};
