@@ -1429,15 +1429,17 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             if (i < qpad) { wq[x] = gw_[i]; lft[i] = gft[i]; lwft[i] = gwft[i]; }
         }
         if (tid < kmax_all) {                                  // Kb <= 256 < threads
-            const int ov = povf[tid], stg = stage[tid];
-            int r = ri0 + tid; if (r >= N) r -= N;
-            const int sl = slot_of[r];
-            osub[tid] = ov; lstage[tid] = stg; lslot[tid] = sl;
+            osub[tid] = povf[tid];
+            if (!pa.g.lazy_rows) {                             // (lazy rows never move: no slot tables)
+                int r = ri0 + tid; if (r >= N) r -= N;
+                lstage[tid] = stage[tid]; lslot[tid] = slot_of[r];
+            }
         }
         for (int i = tid; i < kmax_all * 4; i += T) ssub[i] = scal[i];
         if (tid == 0) { lacc[Kb] = 0; sacc[0] = 0; }
         const double invSw = 1.0 / a.Sw, SIoSw = a.SI / a.Sw, Scen = a.SII - a.SI * a.SI / a.Sw;
         const int resum = pa.g.resum_every;
+        const bool swap_slots = !pa.g.lazy_rows;
         double X = resum ? ch.X : cur.chi2 * nqd;
         bool touched = false, live = true;
         int num_acc_win = 0;
@@ -1513,51 +1515,75 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 const double sc0 = ssub[kg * 4 + 0], sc1 = ssub[kg * 4 + 1], sc2 = ssub[kg * 4 + 2];
                 const int ovg = osub[kg];
                 const double *Gs = Gl + (size_t)(s & 1) * W * W;
-                int start = 0, nacc_sub = 0;
-                for (;;) {
-                    const double SCt = SC + sc0, SICt = SIC + sc1, SCCt = SCC + fma(2., h, sc2);
-                    // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
-                    double S = cSII, num = SICt, den = SCCt;
-                    if (find_bg) {
-                        const double numc = fma(-cSIoSw, SCt, SICt), denc = fma(-(SCt * cinvSw), SCt, SCCt);
-                        const bool neg_b = pos_bg && (fma(cSI, denc, -(numc * SCt)) < 0.);
-                        if (!neg_b) { S = cScen; num = numc; den = denc; }
+                int nacc_sub = 0;
+                // One round per accepted step: every remaining candidate (lanes in `cmask`) is judged against the current
+                // state at once, the first that passes is taken, the state moves on, again from the step behind it.  A round is
+                // a dependent chain on ONE wave — early in a chain, when most proposals pass, the rounds are the whole tick —
+                // so everything that is not on that chain is kept out of it: the candidate and overflow masks are scalars, the
+                // fit flags are compile-time (three copies of the loop), the accepted steps are recorded as a bit mask and
+                // published to LDS once per sub-window, chi²·Q of every candidate is divided out beside its comparison.
+                auto decide = [&](auto fb_t, auto pb_t) {
+                    constexpr bool FB = decltype(fb_t)::value, PB = decltype(pb_t)::value;
+                    const unsigned long long inmask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+                    const unsigned long long ovm_all = __ballot(in && ovg) & inmask;
+                    unsigned long long cmask = inmask, accm = 0ull;
+                    for (;;) {
+                        const double SCt = SC + sc0, SICt = SIC + sc1, SCCt = SCC + fma(2., h, sc2);
+                        // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
+                        double S = cSII, num = SICt, den = SCCt;
+                        if constexpr (FB) {
+                            const double numc = fma(-cSIoSw, SCt, SICt), denc = fma(-(SCt * cinvSw), SCt, SCCt);
+                            if constexpr (PB) {
+                                const bool neg_b = fma(cSI, denc, -(numc * SCt)) < 0.;
+                                if (!neg_b) { S = cScen; num = numc; den = denc; }
+                            } else {
+                                S = cScen; num = numc; den = denc;
+                            }
+                        }
+                        const double n2 = num * num;
+                        double Xc = S - n2 / den;                  // chi²·Q should this candidate be the accepted one
+                        MCSAS_IN_VGPR(Xc);                         // (worked out here, beside the comparison, not behind the ballot)
+                        unsigned long long amask = __ballot(n2 > (S - X) * den) & cmask;   // chi²_t < chi² (mcsas.py:379)
+                        if (never_accept) amask = 0ull;            // diagnostic: never accept
+                        if (amask == 0ull) {
+                            if (ovm_all & cmask) overflow = 1;
+                            num_iter += __builtin_popcountll(cmask);
+                            break;
+                        }
+                        const int ga = __builtin_ctzll(amask);
+                        const unsigned long long upto = (2ull << ga) - 1ull;          // steps 0 .. ga
+                        // the steps behind the accepted one see ft + d_acc: h_k += Σ w d_acc d_k (read issued first)
+                        const double gk = Gs[(size_t)ga * W + (in ? g : 0)];
+                        if (ovm_all & cmask & upto) overflow = 1;
+                        SC = readlane_f64(SCt, ga); SIC = readlane_f64(SICt, ga); SCC = readlane_f64(SCCt, ga);
+                        X = readlane_f64(Xc, ga);
+                        MCSAS_IN_VGPR(SC); MCSAS_IN_VGPR(SIC); MCSAS_IN_VGPR(SCC); MCSAS_IN_VGPR(X);
+                        h += gk;
+                        accm |= 1ull << ga;
+                        num_iter += __builtin_popcountll(cmask & upto);
+                        cmask &= ~upto;
+                        ++num_moves;
+                        if (!(X > cCrit * cnq)) { live = false; break; }
+                        if (cmask == 0ull) break;
                     }
-                    const bool cand = in && g >= start;
-                    const bool acc_g = cand && (num * num > (S - X) * den);   // chi²_t < chi² (mcsas.py:379)
-                    // chi²·Q of every candidate, should it be the accepted one: the same three numbers the decision
-                    // uses, one division, computed beside the comparison instead of behind the ballot
-                    const double Xc = S - num * num / den;
-                    unsigned long long amask = __ballot(acc_g);
-                    if (never_accept) amask = 0ull;                 // diagnostic: never accept
-                    const unsigned long long ovm = __ballot(cand && ovg);
-                    if (amask == 0ull) {
-                        if (ovm) overflow = 1;
-                        num_iter += cnt - start;
-                        break;
+                    // the accepted steps of the sub-window, in order: sacc[1 + i] = step in the sub-window, lacc[...] = step in the window
+                    nacc_sub = __builtin_popcountll(accm);
+                    if ((accm >> lane) & 1ull) {
+                        const int pos = __builtin_popcountll(accm & ((1ull << lane) - 1ull));
+                        const int acc_row = k0 + lane;
+                        sacc[1 + pos] = lane;
+                        lacc[num_acc_win + pos] = acc_row;
+                        if (swap_slots) {                          // slot swap: rows are never copied (lazy rows never move: nothing to swap)
+                            const int fresh = lstage[acc_row], freed = lslot[acc_row];
+                            lslot[acc_row] = fresh; lstage[acc_row] = freed;
+                        }
                     }
-                    const int ga = __builtin_ctzll(amask);
-                    if (ovm & ((2ull << ga) - 1ull)) overflow = 1;
-                    const int acc_row = k0 + ga;
-                    // the steps behind the accepted one see ft + d_acc: h_k += Σ w d_acc d_k (read issued first)
-                    const double gk = Gs[(size_t)ga * W + (in ? g : 0)];
-                    const int fresh = lstage[acc_row], freed = lslot[acc_row];
-                    SC = readlane_f64(SCt, ga); SIC = readlane_f64(SICt, ga); SCC = readlane_f64(SCCt, ga);
-                    X = readlane_f64(Xc, ga);
-                    MCSAS_IN_VGPR(SC); MCSAS_IN_VGPR(SIC); MCSAS_IN_VGPR(SCC); MCSAS_IN_VGPR(X);
-                    h += gk;
-                    if (lane == 0) {
-                        lslot[acc_row] = fresh; lstage[acc_row] = freed;      // slot swap: rows are never copied
-                        lacc[num_acc_win] = acc_row;
-                        sacc[1 + nacc_sub] = ga;
-                    }
-                    ++nacc_sub; ++num_acc_win; ++num_moves;
-                    touched = true;
-                    num_iter += ga + 1 - start;
-                    start = ga + 1;
-                    if (!(X > cCrit * cnq)) { live = false; break; }
-                    if (start >= cnt) break;
-                }
+                    num_acc_win += nacc_sub;
+                    if (nacc_sub) touched = true;
+                };
+                if (!find_bg) decide(std::false_type{}, std::false_type{});
+                else if (pos_bg) decide(std::true_type{}, std::true_type{});
+                else decide(std::true_type{}, std::false_type{});
                 cur.chi2 = X / cnq;                               // scale and background are only needed at the end of the attempt
                 if (lane == 0) { sacc[0] = nacc_sub; ctl[2] = live ? 1 : 0; }
                 __builtin_amdgcn_s_setprio(0);
