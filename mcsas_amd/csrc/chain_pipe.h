@@ -1527,9 +1527,16 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     const unsigned long long inmask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
                     const unsigned long long ovm_all = __ballot(in && ovg) & inmask;
                     unsigned long long cmask = inmask, accm = 0ull;
+                    // The current state's chi²·Q enters a comparison as the pair (Na, Da), X = Sa - Na / Da, with (S - X, 1) at the
+                    // head of a sub-window — "chi²_t < chi²" (mcsas.py:379), num² / den > Na / Da + (S - Sa), is taken across:
+                    // num² Da > (Na + (S - Sa) Da) den.  With (S - X, 1) that is the very expression num² > (S - X) den; behind an
+                    // accepted step it is that step's own (num², den), exact, and the division that gives X leaves the chain of
+                    // dependent operations a round consists of (it is made once, when the sub-window is through).  S is the same
+                    // for every candidate unless positiveBackground can switch a candidate to the uncentred sums.
+                    double Sa = PB ? X : 0., Na = PB ? 0. : (FB ? cScen : cSII) - X, Da = 1.0;
+                    MCSAS_IN_VGPR(Na); MCSAS_IN_VGPR(Da);
                     for (;;) {
                         const double SCt = SC + sc0, SICt = SIC + sc1, SCCt = SCC + fma(2., h, sc2);
-                        // chi²·Q = S - num²/den for the candidate (centred sums when a background is fitted)
                         double S = cSII, num = SICt, den = SCCt;
                         if constexpr (FB) {
                             const double numc = fma(-cSIoSw, SCt, SICt), denc = fma(-(SCt * cinvSw), SCt, SCCt);
@@ -1541,9 +1548,15 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                             }
                         }
                         const double n2 = num * num;
-                        double Xc = S - n2 / den;                  // chi²·Q should this candidate be the accepted one
-                        MCSAS_IN_VGPR(Xc);                         // (worked out here, beside the comparison, not behind the ballot)
-                        unsigned long long amask = __ballot(n2 > (S - X) * den) & cmask;   // chi²_t < chi² (mcsas.py:379)
+                        bool pass, conv;
+                        if constexpr (PB) {
+                            pass = n2 * Da > fma(S - Sa, Da, Na) * den;
+                        } else {
+                            pass = n2 * Da > Na * den;
+                        }
+                        conv = !((S - cCrit * cnq) * den > n2);      // this candidate, accepted, ends the attempt: !(chi² > criterion)
+                        unsigned long long amask = __ballot(pass) & cmask;
+                        const unsigned long long convm = __ballot(conv);
                         if (never_accept) amask = 0ull;            // diagnostic: never accept
                         if (amask == 0ull) {
                             if (ovm_all & cmask) overflow = 1;
@@ -1556,18 +1569,24 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                         const double gk = Gs[(size_t)ga * W + (in ? g : 0)];
                         if (ovm_all & cmask & upto) overflow = 1;
                         SC = readlane_f64(SCt, ga); SIC = readlane_f64(SICt, ga); SCC = readlane_f64(SCCt, ga);
-                        X = readlane_f64(Xc, ga);
-                        MCSAS_IN_VGPR(SC); MCSAS_IN_VGPR(SIC); MCSAS_IN_VGPR(SCC); MCSAS_IN_VGPR(X);
+                        Na = readlane_f64(n2, ga); Da = readlane_f64(den, ga);
+                        MCSAS_IN_VGPR(SC); MCSAS_IN_VGPR(SIC); MCSAS_IN_VGPR(SCC); MCSAS_IN_VGPR(Na); MCSAS_IN_VGPR(Da);
+                        if constexpr (PB) { Sa = readlane_f64(S, ga); MCSAS_IN_VGPR(Sa); }
                         h += gk;
                         accm |= 1ull << ga;
                         num_iter += __builtin_popcountll(cmask & upto);
                         cmask &= ~upto;
                         ++num_moves;
-                        if (!(X > cCrit * cnq)) { live = false; break; }
+                        if ((convm >> ga) & 1ull) { live = false; break; }
                         if (cmask == 0ull) break;
                     }
                     // the accepted steps of the sub-window, in order: sacc[1 + i] = step in the sub-window, lacc[...] = step in the window
                     nacc_sub = __builtin_popcountll(accm);
+                    if (nacc_sub) {
+                        X = (PB ? Sa : (FB ? cScen : cSII)) - Na / Da;   // chi²·Q of the state the sub-window ends in
+                        MCSAS_IN_VGPR(X);
+                        touched = true;
+                    }
                     if ((accm >> lane) & 1ull) {
                         const int pos = __builtin_popcountll(accm & ((1ull << lane) - 1ull));
                         const int acc_row = k0 + lane;
@@ -1579,7 +1598,6 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                         }
                     }
                     num_acc_win += nacc_sub;
-                    if (nacc_sub) touched = true;
                 };
                 if (!find_bg) decide(std::false_type{}, std::false_type{});
                 else if (pos_bg) decide(std::true_type{}, std::true_type{});

@@ -5,11 +5,11 @@ set -e
 cd $(dirname $0)/../mcsas_amd/csrc
 name=$1; shift
 B=../../build/csrc; V=../../build/variant_$name; mkdir -p $V
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value $*"
+F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value -I$B $*"
 /opt/rocm/bin/hipcc $F -c -o $V/mcsas_hip.o mcsas_hip.hip &
 /opt/rocm/bin/hipcc $F -DMCSAS_M=0 -c -o $V/kern_pipe_m0.o kern_pipe.hip &
 wait
 objs="$V/mcsas_hip.o $V/kern_pipe_m0.o"
-for m in 0 1 2 3 4 5 6 7; do objs="$objs $B/kern_wave_m$m.o $B/kern_wg_m$m.o"; [ $m != 0 ] && objs="$objs $B/kern_pipe_m$m.o"; done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/libmcsas_$name.so $objs
+for m in 0 1 2 3 4 5 6 7; do objs="$objs $B/kern_wave_m$m.o $B/kern_wg_m$m.o $B/kern_wide_m$m.o"; [ $m != 0 ] && objs="$objs $B/kern_pipe_m$m.o"; done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../lib/libmcsas_$name.so $objs -lhiprtc
 ls -la ../lib/libmcsas_$name.so
