@@ -262,7 +262,8 @@ int mcsas_hip_rebin(int32_t n, const double *x, const double *f, const double *f
  * (csrc/fastmath.h and device_util.h are in scope, namespace mcsas.)  The text is compiled with hiprtc for gfx950 against
  * the library's own kernel headers, which it carries inside; no GPU is needed for that.  *model_id (>= MCSAS_MODEL_PLUGIN0)
  * is then valid as mcsas_problem.model_id in every entry point and every execution mode (the chain kernel of the mode is
- * compiled for the plug-in on first use: 0.5 - 15 s once per q-slot count), nq <= 1024; beam-profile smearing if the text
+ * compiled for the plug-in on first use: 0.5 - 15 s once per q-slot count; more than 1024 q-points: the q-split workgroup
+ * kernel, MCSAS_EXEC_AUTO or MCSAS_EXEC_WORKGROUP); beam-profile smearing if the text
  * says `#define MCSAS_PLUGIN_CAN_SMEAR 1` (the model class's canSmear).  A form
  * factor that loops over orientations / a contour should say `#define MCSAS_PLUGIN_ROW_CLASS 1` (csrc/plugin_model.h: how
  * the pipeline spreads such rows over the chip; results do not depend on it).  The same text registered twice

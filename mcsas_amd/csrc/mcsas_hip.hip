@@ -200,7 +200,7 @@ static int plugin_compile_program(const std::string &source, const std::vector<s
         "typedef int int32_t; typedef unsigned int uint32_t; typedef long int64_t; typedef unsigned long uint64_t;\n"
         "#include \"chain_common.h\"\n#line 1 \"plugin\"\n";
     tu += source;
-    tu += "\n#include \"plugin_model.h\"\n#include \"chain_wave.h\"\n#include \"chain_wg.h\"\n#include \"chain_pipe.h\"\n#include \"small_kernels.h\"\n";
+    tu += "\n#include \"plugin_model.h\"\n#include \"chain_wave.h\"\n#include \"chain_wg.h\"\n#include \"chain_wide.h\"\n#include \"chain_pipe.h\"\n#include \"small_kernels.h\"\n";
     hiprtcProgram prog = nullptr;
     hiprtcResult r = hiprtcCreateProgram(&prog, tu.c_str(), "mcsas_plugin.hip", mcsas_embedded_count, const_cast<const char **>(mcsas_embedded_texts),
                                          const_cast<const char **>(mcsas_embedded_names));
@@ -264,6 +264,12 @@ static int plugin_wg_function(int model_id, int qpl, hipFunction_t *fn) {
     char e[128], k[32];
     snprintf(e, sizeof e, "mcsas::chain_wg_kernel<MCSAS_MODEL_PLUGIN, %d>", qpl);
     snprintf(k, sizeof k, "wg %d", qpl);
+    return plugin_function(model_id, k, {e}, e, fn);
+}
+static int plugin_wide_function(int model_id, int qpl, hipFunction_t *fn) {
+    char e[128], k[32];
+    snprintf(e, sizeof e, "mcsas::chain_wide_kernel<MCSAS_MODEL_PLUGIN, %d>", qpl);
+    snprintf(k, sizeof k, "wide %d", qpl);
     return plugin_function(model_id, k, {e}, e, fn);
 }
 static int plugin_pipe_function(int model_id, int qpl, hipFunction_t *fn) {
@@ -619,10 +625,9 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     // up to 4096 / 8192 / 16384 q-points) — MCSAS_EXEC_WORKGROUP, and what MCSAS_EXEC_AUTO picks; up to 4096 q-points
     // MCSAS_EXEC_WAVE still runs one wavefront per chain with 32 / 64 slots per lane
     const bool wide_q = p->nq > 16 * WAVE;
-    const bool plugin_early = is_plugin_model(p->model_id);
     bool wide = false;
     int wide_waves = 0;
-    if (wide_q && !plugin_early) {
+    if (wide_q) {
         const bool wave_asked = p->exec_mode == MCSAS_EXEC_WAVE || (p->exec_mode == MCSAS_EXEC_AUTO && p->waves_per_chain == 1);
         if (p->exec_mode == MCSAS_EXEC_PIPELINE) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 1024: the pipeline has no kernels for it (exec_mode 0, 1 or 2)", p->nq); }
         if (p->nq > WIDE_MAX_WAVES * WAVE * 32) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "nq %d > 16384 is not supported", p->nq); }
@@ -657,9 +662,9 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     int mode = p->exec_mode;
     int waves = p->waves_per_chain;
     const bool plugin = is_plugin_model(p->model_id);
-    if (plugin && wide_q) {
+    if (plugin && wide_q && !wide) {
         mcsas_hip_plan_destroy(pl);
-        return fail(MCSAS_EINVAL, "model plug-ins: up to 1024 q-points (nq %d asked)", p->nq);
+        return fail(MCSAS_EINVAL, "model plug-ins: more than 1024 q-points run one workgroup per chain only (exec_mode 0 or 2; nq %d, exec_mode %d asked)", p->nq, p->exec_mode);
     }
     if (mode == MCSAS_EXEC_AUTO) {
         if (waves == 1) mode = MCSAS_EXEC_WAVE;
@@ -790,7 +795,10 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         const size_t with_q = base + sizeof(double) * 2 * (size_t)qpad;
         a.pad1 = with_q <= 150 * 1024 ? 1 : 0;
         pl->lds_bytes = a.pad1 ? with_q : base;
-        if (!wide_kernel_for(p->model_id, qpl)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no q-split kernel for model %d qpl %d", p->model_id, qpl); }
+        if (plugin) {
+            rc = plugin_wide_function(p->model_id, qpl, &pl->plugin_fn);
+            if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
+        } else if (!wide_kernel_for(p->model_id, qpl)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "no q-split kernel for model %d qpl %d", p->model_id, qpl); }
     } else if (mode == MCSAS_EXEC_WORKGROUP) {
         pl->lds_bytes = pl->wg.lds_bytes;
         if (plugin) {
@@ -923,7 +931,7 @@ extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
     void *fn;
     dim3 grid(pl->prob.n_reps), block;
     if (pl->plugin_fn) {                                  // a run-time model plug-in: the same arguments, through its code-object module
-        void *kargs2[] = {(void *)&pl->args, (void *)&pl->wg};
+        void *kargs2[] = {(void *)&pl->args, pl->wide ? (void *)&pl->d_q3inv : (void *)&pl->wg};
         const bool wgm = pl->mode == MCSAS_EXEC_WORKGROUP;
         HIPCHK(hipEventRecord(pl->ev0, st));
         HIPCHK(hipModuleLaunchKernel(pl->plugin_fn, grid.x, 1, 1, wgm ? WAVE * pl->waves : WAVE, 1, 1, (unsigned)pl->lds_bytes, st,

@@ -1018,10 +1018,18 @@ def test_plugin_model_replays_the_reference_and_equals_its_built_in_twin(tag, na
         assert np.array_equal(a, b)
     for a, b in zip(engine.histogram_prep(setup, q, I, sig, ref.contribs, st.comp_exp, st.find_background, st.positive_background), prep_ref):
         assert np.array_equal(a, b)
-    # more than 1024 q-points have no plug-in kernels: refused, not silently replaced
+    # more than 1024 q-points: the q-split workgroup kernel, compiled for the plug-in like the others (what auto picks); one
+    # wavefront per chain is refused for a plug-in there, not silently replaced
     qw, Iw, sw = _synthetic(1500)
+    stw = engine.Settings(n_contrib=24, n_reps=2, max_iter=60, conv_crit=1e-9, max_retries=0, seed=3)
+    wide = engine.analyse(setup, qw, Iw, sw, stw)
+    m2, _ = make_models(tag, g["spec_lo"], g["spec_hi"], [int(x) for x in g["spec_gen"]])
+    for p_, p2 in zip(m.params(), m2.params()):
+        p2.setValue(p_())
+    twin = engine.analyse(m2.setup(), qw, Iw, sw, stw)
+    assert twin.num_moves.sum() > 0 and np.array_equal(wide.contribs, twin.contribs) and np.array_equal(wide.fit, twin.fit)
     with pytest.raises(mcsas_amd._lib.McSASHipError) as e:
-        engine.analyse(setup, qw, Iw, sw, engine.Settings(n_contrib=20, n_reps=1, max_iter=10, conv_crit=0.0, max_retries=0))
+        engine.analyse(setup, qw, Iw, sw, engine.Settings(**{**stw.__dict__, "exec_mode": engine.EXEC_WAVE}))
     assert e.value.code == -1
 
 
