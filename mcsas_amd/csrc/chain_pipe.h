@@ -1188,34 +1188,30 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         const unsigned long long mask = __ballot(lane < BR && rank == target);
         return (int)__builtin_ctzll(mask | (1ull << 63));          // (every rank 0 .. BR-1 is taken exactly once)
     };
-    // the `old` row of my next row is requested before the current one is evaluated
-    double ocur[QPL], onext[QPL];
+    // The `old` row of a step is read BEHIND the evaluation of its `new` row: a row with an integral takes tens of microseconds,
+    // the load two, and the sixteen or thirty-two registers a row requested ahead would occupy across the evaluation are the
+    // difference between the integrand's inner loops running from registers or from scratch.
     int lr = my_row(0);
-    {
-        const auto orow0 = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, lr) * qpad + lane;
-        PIPE_TLX_MARK(pa, t, 2);
-#pragma unroll
-        for (int j = 0; j < QPL; ++j) ocur[j] = orow0[WAVE * j];
-    }
-    PIPE_PIN_ROW(ocur);                                           // (a pending load carried into the loop would be waited for at its head, every iteration)
+    PIPE_TLX_MARK(pa, t, 2);
     PIPE_TLX_MARK(pa, t, 3);
     for (int i = 0; i < rpw; ++i) {
         const int bl = __builtin_amdgcn_readfirstlane(lr);       // block row of this iteration
         const int k = kb0 + bl;
         const int lr_next = i + 1 < rpw ? my_row(i + 1) : lr;
-        {
-            const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, lr_next) * qpad + lane;
-#pragma unroll
-            for (int j = 0; j < QPL; ++j) onext[j] = orow[WAVE * j];
-        }
         if (s0 + bl < max_iter) {                                 // uniform in the wave (rows behind max_iter rank last)
             const Contrib<M> cnew = prop.bcast(bl);
             const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
             const auto nrow = cache + (size_t)sslot * qpad + lane;
             const auto dr = dwin + (size_t)k * qpad + lane;
-            double d[QPL], nwv[QPL];
+            double d[QPL], nwv[QPL], ocur[QPL];
             RowEval<M, QPL>::run(cnew, qt, lane, nwv);
-            PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
+            PIPE_PIN_ROW(nwv);
+            {
+                const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bl) * qpad + lane;
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) ocur[j] = orow[WAVE * j];
+            }
+            PIPE_PIN_ROW(ocur);                                   // the `old` row has landed before the first store is issued
             // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  (Taking the
             // sums in the scan block's pass over the row instead was measured: its single h pass is the serial part of a
             // tick, 5x the dot-product work there cost 8 us per tick, here it is spread over every CU.)
@@ -1239,11 +1235,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                 }
             const int ov = __builtin_amdgcn_readlane(pov, bl);
             if (lane == 0) povf[k] = ov;
-        } else {
-            PIPE_PIN_ROW(onext);
         }
-#pragma unroll
-        for (int j = 0; j < QPL; ++j) ocur[j] = onext[j];
         lr = lr_next;
     }
     // ---- the sub-window's Gram block from the d rows the block has just written (workgroup-scope visibility:
