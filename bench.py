@@ -209,7 +209,7 @@ def main():
                     help="skip the untimed run-to-convergence (profiling: only the timed launches reach the profiler)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of configs 3-5")
     ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic role ablation (invalid results)")
-    ap.add_argument("--inflight", type=int, default=2, help="analyses in flight on this rank (plans taking turns on one stream); 1 = one after the other")
+    ap.add_argument("--inflight", type=int, default=2, help="analyses in flight on this rank (the plan's two result slots); 1 = one after the other")
     ap.add_argument("--dump", default="", help="rank 0: write the gathered arrays of the last launch to this .npz (tests)")
     args = ap.parse_args()
 
@@ -267,11 +267,11 @@ def main():
                              max_retries=0, seed=20250101, rep_offset=first, device=dev_index,
                              waves_per_chain=args.waves, exec_mode=args.mode, debug_flags=args.debug_flags)
         plan = engine.Plan(setup, q, I, sigma, st)
-    # Analyses in flight: every launch is a complete analyse() of this rank's repetitions whose results come back to the host;
-    # with TWO plans (two sets of workspaces) taking turns on one stream the next analysis is already queued while the
-    # previous one's results are fetched and unpacked, so the GPU does not idle for the host (a series of data sets,
-    # mcsas_amd.run_series, is the use case).  --inflight 1: strictly one after the other.
-    plans = [plan] + ([] if dry else [engine.Plan(setup, q, I, sigma, st) for _ in range(max(args.inflight, 1) - 1)])
+    # Analyses in flight: every launch is a complete analyse() of this rank's repetitions whose results come back to the host.
+    # The plan has two RESULT SLOTS over one set of workspaces (mcsas_hip_plan_launch_slot): the next analysis is already queued
+    # on the stream while the previous one's results are fetched and unpacked, so the GPU does not idle for the host (a series
+    # of data sets, mcsas_amd.run_series, is the use case).  --inflight 1: strictly one after the other.
+    nslots = 1 if dry else max(1, min(args.inflight, 2))
 
     launch_ms = []
     gathered = {}
@@ -279,23 +279,25 @@ def main():
     state = {"mc": 0, "res": None, "n": 0}
 
     def retire():
-        pl = pending.pop(0)
-        res = pl.fetch()
-        launch_ms.append(pl.last_ms)
-        state["mc"] += pl.total_steps
+        slot = pending.pop(0)
+        res = plan.fetch() if dry else plan.fetch(slot=slot)
+        launch_ms.append(plan.last_ms)
+        state["mc"] += plan.total_steps
         state["res"] = res
         return res
 
     def one_launch(seed):
-        pl = plans[state["n"] % len(plans)]
+        slot = state["n"] % nslots
         state["n"] += 1
-        if pl in pending:                                 # (its previous analysis must be home before it is started again)
-            while pl in pending:
-                retire()
-        pl.reseed(seed, first)
-        pl.launch()
-        pending.append(pl)
-        while len(pending) >= len(plans):
+        while slot in pending:                            # (its previous analysis must be home before the slot is written again)
+            retire()
+        plan.reseed(seed, first)
+        if dry:
+            plan.launch()
+        else:
+            plan.launch(slot=slot)
+        pending.append(slot)
+        while len(pending) >= nslots:
             retire()
 
     def drain():

@@ -197,6 +197,14 @@ int  mcsas_hip_plan_create(const mcsas_problem *problem, mcsas_plan **plan);
 int  mcsas_hip_plan_launch(mcsas_plan *plan, void *hip_stream);
 /* wait for the launch (forwarding problem->stop meanwhile) and copy results out */
 int  mcsas_hip_plan_fetch(mcsas_plan *plan, mcsas_result *result);
+/* Result slots.  A plan keeps MCSAS_PLAN_SLOTS sets of what a finished analysis is read back from (parameter sets, fits,
+ * per-chain outputs, timing events) over ONE set of workspaces, so that a series of analyses — one data set after the other,
+ * gui/calc.py:271-330 — keeps the device busy: launch into slot 1 while slot 0 is being fetched and unpacked.  The slots of a
+ * plan share its workspaces: launch them on the same stream (they then run one after the other).  mcsas_hip_plan_launch /
+ * _fetch are slot 0; _last_ms and _total_steps report the slot fetched last. */
+#define MCSAS_PLAN_SLOTS 2
+int  mcsas_hip_plan_launch_slot(mcsas_plan *plan, void *hip_stream, int32_t slot);
+int  mcsas_hip_plan_fetch_slot(mcsas_plan *plan, int32_t slot, mcsas_result *result);
 /* device time of the last launch measured with HIP events on its stream, milliseconds */
 int  mcsas_hip_plan_last_ms(mcsas_plan *plan, double *ms);
 /* total MC steps executed by the last launch (sum of iterations over chains and attempts) */

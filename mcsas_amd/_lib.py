@@ -22,6 +22,7 @@ LIB_PATH = os.environ.get("MCSAS_HIP_LIB") or os.path.join(os.path.dirname(os.pa
 # every symbol include/mcsas_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = (
     "mcsas_hip_analyse", "mcsas_hip_shard", "mcsas_hip_plan_create", "mcsas_hip_plan_launch", "mcsas_hip_plan_fetch",
+    "mcsas_hip_plan_launch_slot", "mcsas_hip_plan_fetch_slot",
     "mcsas_hip_plan_last_ms", "mcsas_hip_plan_total_steps", "mcsas_hip_plan_reseed", "mcsas_hip_plan_info",
     "mcsas_hip_plan_destroy", "mcsas_hip_model_calc", "mcsas_hip_bgfit", "mcsas_hip_observability",
     "mcsas_hip_histogram_prep", "mcsas_hip_prepare_uncertainty", "mcsas_hip_rebin",
@@ -111,6 +112,8 @@ def load(tuning=False):
     lib.mcsas_hip_plan_create.argtypes = [C.POINTER(Problem), C.POINTER(C.c_void_p)]
     lib.mcsas_hip_plan_launch.argtypes = [C.c_void_p, C.c_void_p]
     lib.mcsas_hip_plan_fetch.argtypes = [C.c_void_p, C.POINTER(Result)]
+    lib.mcsas_hip_plan_launch_slot.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.mcsas_hip_plan_fetch_slot.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Result)]
     lib.mcsas_hip_plan_last_ms.argtypes = [C.c_void_p, _dp]
     lib.mcsas_hip_plan_total_steps.argtypes = [C.c_void_p, _i64p]
     lib.mcsas_hip_plan_reseed.argtypes = [C.c_void_p, C.c_uint64, C.c_int32]

@@ -495,7 +495,54 @@ struct mcsas_plan {
     static constexpr int RING = 64;
     hipEvent_t evP[RING] = {}, evS[RING] = {};
     int ticks_launched = 0;
+    // Result slots (mcsas_hip_plan_launch_slot / _fetch_slot): everything a finished analysis is read back from — parameter
+    // sets, fits, per-chain outputs, the timing events, the host-visible "all chains done" word — exists MCSAS_PLAN_SLOTS times,
+    // the workspaces (row cache, window buffers, chain records) once.  The plan's own members above are the view of the slot
+    // that was last activated; the others are parked here.
+    struct Slot {
+        double *d_rset = nullptr, *d_fit = nullptr;
+        ChainOut *d_out = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        int32_t *h_done = nullptr, *d_done_map = nullptr;
+        PipeArgs *h_pipeargs = nullptr;
+        bool launched = false, made = false;
+        int ticks_launched = 0;
+        double last_ms = 0.;
+        int64_t last_steps = 0;
+    };
+    Slot slots[MCSAS_PLAN_SLOTS];
+    int cur_slot = 0;
 };
+
+// make slot k the plan's active view (allocating it on first use)
+static int plan_activate_slot(mcsas_plan *pl, int k) {
+    if (k < 0 || k >= MCSAS_PLAN_SLOTS) return fail(MCSAS_EINVAL, "slot %d (0..%d)", k, MCSAS_PLAN_SLOTS - 1);
+    if (k == pl->cur_slot) return MCSAS_OK;
+    mcsas_plan::Slot &o = pl->slots[pl->cur_slot], &n = pl->slots[k];
+    o.d_rset = pl->d_rset; o.d_fit = pl->d_fit; o.d_out = pl->d_out; o.ev0 = pl->ev0; o.ev1 = pl->ev1; o.h_done = pl->h_done;
+    o.d_done_map = pl->pipe.n_done; o.h_pipeargs = pl->h_pipeargs; o.launched = pl->launched; o.ticks_launched = pl->ticks_launched;
+    o.last_ms = pl->last_ms; o.last_steps = pl->last_steps; o.made = true;
+    if (!n.made) {
+        const size_t R = pl->prob.n_reps, N = pl->prob.n_contrib, P = pl->prob.n_active, qpad = pl->args.qpad;
+        HIPCHK(pl->pool.get(&n.d_rset, sizeof(double) * R * N * P));
+        HIPCHK(pl->pool.get(&n.d_fit, sizeof(double) * R * qpad));
+        HIPCHK(pl->pool.get(&n.d_out, sizeof(ChainOut) * R));
+        HIPCHK(hipMemset(n.d_out, 0, sizeof(ChainOut) * R));
+        HIPCHK(hipEventCreate(&n.ev0)); HIPCHK(hipEventCreate(&n.ev1));
+        if (pl->mode == MCSAS_EXEC_PIPELINE) {
+            HIPCHK(hipHostMalloc((void **)&n.h_done, sizeof(int32_t), hipHostMallocMapped));
+            *n.h_done = 0;
+            HIPCHK(hipHostGetDevicePointer((void **)&n.d_done_map, n.h_done, 0));
+        }
+        n.made = true;
+    }
+    pl->d_rset = n.d_rset; pl->d_fit = n.d_fit; pl->d_out = n.d_out; pl->ev0 = n.ev0; pl->ev1 = n.ev1; pl->h_done = n.h_done;
+    pl->pipe.n_done = n.d_done_map; pl->h_pipeargs = n.h_pipeargs; pl->launched = n.launched; pl->ticks_launched = n.ticks_launched;
+    pl->last_ms = n.last_ms; pl->last_steps = n.last_steps;
+    pl->args.rset = pl->d_rset; pl->args.fit = pl->d_fit; pl->args.out = pl->d_out;
+    pl->cur_slot = k;
+    return MCSAS_OK;
+}
 
 // kernel lookups, one translation unit per model (kern_wave.hip / kern_wg.hip)
 #define DECL_K(m) void *mcsas_wave_kernel_m##m(int, bool); void *mcsas_wg_kernel_m##m(int); void *mcsas_wide_kernel_m##m(int); void *mcsas_pipe_tick_kernel_m##m(int);
@@ -552,6 +599,14 @@ extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     if (pl->sS) hipStreamDestroy(pl->sS);
     if (pl->ev0) hipEventDestroy(pl->ev0);
     if (pl->ev1) hipEventDestroy(pl->ev1);
+    for (int k = 0; k < MCSAS_PLAN_SLOTS; ++k) {          // the parked result slots (the active one's members were freed above)
+        if (k == pl->cur_slot || !pl->slots[k].made) continue;
+        mcsas_plan::Slot &sl = pl->slots[k];
+        if (sl.h_done) hipHostFree(sl.h_done);
+        if (sl.h_pipeargs) hipHostFree(sl.h_pipeargs);
+        if (sl.ev0) hipEventDestroy(sl.ev0);
+        if (sl.ev1) hipEventDestroy(sl.ev1);
+    }
     delete pl;
 }
 
@@ -915,10 +970,14 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     return MCSAS_OK;
 }
 
-extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
+extern "C" int mcsas_hip_plan_launch_slot(mcsas_plan *pl, void *hip_stream, int32_t slot) {
     if (!pl) return fail(MCSAS_EINVAL, "null plan");
     DeviceGuard dev_guard;
     HIPCHK(hipSetDevice(pl->dev));
+    {
+        int rcs = plan_activate_slot(pl, slot);
+        if (rcs) return rcs;
+    }
     hipStream_t st = (hipStream_t)hip_stream;
     *pl->h_stop = (pl->prob.stop && *pl->prob.stop) ? 1 : 0;
     if (pl->mode == MCSAS_EXEC_PIPELINE) {
@@ -968,8 +1027,16 @@ extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) {
     return MCSAS_OK;
 }
 
-extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
+extern "C" int mcsas_hip_plan_launch(mcsas_plan *pl, void *hip_stream) { return mcsas_hip_plan_launch_slot(pl, hip_stream, 0); }
+
+extern "C" int mcsas_hip_plan_fetch_slot(mcsas_plan *pl, int32_t slot, mcsas_result *res) {
     if (!pl) return fail(MCSAS_EINVAL, "null plan");
+    {
+        DeviceGuard dg;
+        HIPCHK(hipSetDevice(pl->dev));
+        int rcs = plan_activate_slot(pl, slot);
+        if (rcs) return rcs;
+    }
     if (!pl->launched) return fail(MCSAS_EINVAL, "plan was not launched");
     if (res && res->struct_size != sizeof(mcsas_result))
         return fail(MCSAS_EINVAL, "mcsas_result size %u, library expects %zu", res->struct_size, sizeof(mcsas_result));
@@ -1062,6 +1129,8 @@ extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) {
     if (ovf) return fail(MCSAS_ESTREAM, "replay stream exhausted (replay_len=%lld)", (long long)pl->prob.replay_len);
     return MCSAS_OK;
 }
+
+extern "C" int mcsas_hip_plan_fetch(mcsas_plan *pl, mcsas_result *res) { return mcsas_hip_plan_fetch_slot(pl, 0, res); }
 
 extern "C" int mcsas_hip_plan_info(mcsas_plan *pl, int32_t info[8]) {
     if (!pl || !info) return fail(MCSAS_EINVAL, "null argument");

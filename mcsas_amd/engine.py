@@ -197,13 +197,15 @@ class Plan:
         self.h = C.c_void_p()
         check(self.lib.mcsas_hip_plan_create(C.byref(self.prob.c), C.byref(self.h)), self.lib)
 
-    def launch(self, stream=None):
-        check(self.lib.mcsas_hip_plan_launch(self.h, C.c_void_p(stream or 0)), self.lib)
+    def launch(self, stream=None, slot=0):
+        """Enqueues one analysis.  `slot`: which of the plan's result sets (mcsas_hip.h: MCSAS_PLAN_SLOTS) it writes — launch
+        into slot 1 while slot 0 is fetched and the device never waits for the host (same stream: the slots share the workspaces)."""
+        check(self.lib.mcsas_hip_plan_launch_slot(self.h, C.c_void_p(stream or 0), C.c_int32(slot)), self.lib)
 
-    def fetch(self, want_arrays=True):
+    def fetch(self, want_arrays=True, slot=0):
         st = self.prob.st
         res = ChainResults(st.n_contrib, self.prob.model.n_active, st.n_reps, len(self.prob.q)) if want_arrays else None
-        check(self.lib.mcsas_hip_plan_fetch(self.h, C.byref(res.c) if res is not None else None), self.lib)
+        check(self.lib.mcsas_hip_plan_fetch_slot(self.h, C.c_int32(slot), C.byref(res.c) if res is not None else None), self.lib)
         return res
 
     def reseed(self, seed, rep_offset=0):

@@ -1201,3 +1201,29 @@ def test_plugin_model_with_can_smear_matches_the_reference_smeared_intensities()
     np.testing.assert_array_equal(out[0].contribs, out[1].contribs)
     unsmeared = engine.analyse(m.setup(), q, I, sig, engine.Settings(n_contrib=40, n_reps=3, max_iter=300, conv_crit=1e-9, max_retries=0, seed=4, exec_mode=engine.EXEC_WAVE))
     assert not np.array_equal(unsmeared.contribs, out[0].contribs)
+
+
+@pytest.mark.parametrize("mode", [engine.EXEC_PIPELINE, engine.EXEC_WAVE, engine.EXEC_WORKGROUP])
+def test_result_slots_keep_two_analyses_apart(mode):
+    """mcsas_hip_plan_launch_slot / _fetch_slot: two analyses queued back to back on one stream into the plan's two result
+    slots (one set of workspaces) come back exactly as when each is run alone — also when slot 0 is launched again before
+    slot 1 has been fetched."""
+    g = load("g4_sphere_q100_fixed.npz")
+    q, I, sig = g["data_q"], g["data_I"], g["data_sigma"]
+    m, _ = make_models("sphere", g["spec_lo"], g["spec_hi"])
+    st = engine.Settings(n_contrib=200, n_reps=6, max_iter=2500, conv_crit=0.5, max_retries=1, seed=1, exec_mode=mode)
+    alone = {}
+    for seed in (11, 12, 13):
+        alone[seed] = engine.analyse(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "seed": seed}))
+    pl = engine.Plan(m.setup(), q, I, sig, st)
+    pl.reseed(11); pl.launch(slot=0)
+    pl.reseed(12); pl.launch(slot=1)
+    a = pl.fetch(slot=0)
+    pl.reseed(13); pl.launch(slot=0)
+    b = pl.fetch(slot=1)
+    c = pl.fetch(slot=0)
+    for got, seed in ((a, 11), (b, 12), (c, 13)):
+        for name in ("contribs", "fit", "chisq", "num_iter", "num_moves", "attempts", "converged"):
+            np.testing.assert_array_equal(getattr(got, name), getattr(alone[seed], name), err_msg="%s seed %d" % (name, seed))
+    with pytest.raises(mcsas_amd._lib.McSASHipError):
+        pl.launch(slot=2)
