@@ -58,7 +58,9 @@ def main():
     commit = sys.argv[1] if len(sys.argv) > 1 else "?"
     md = ["# Round 3 profiles (MI355X, rocprofv3; raw passes by tools/profile_r03.sh, this file by tools/pmc_summary_r03.py)", "",
           "Counter passes run with `--kernel-trace --pmc ...` only, the bench program directly after `--`; every pass is its own run.",
-          "SQ_* counters are sums over all shader engines of the dispatches of the named kernel; *_CYCLES in quad-cycles.", ""]
+          "SQ_* counters are sums over all shader engines of the dispatches of the named kernel; *_CYCLES in quad-cycles.",
+          "Kernel durations under `--kernel-trace` run ~6 % above the un-profiled ones (config 2: 107 ticks x the average below = the launch time "
+          "the bench reports UNDER the same pass; profiles/r03_bench_line.json, taken without a profiler, has 3.40 ms per launch).", ""]
     valu = {}
     works = [("c2", 2, r"pipe_tick_kernel"), ("c3", 3, r"pipe_tick_kernel"), ("c4", 4, r"pipe_tick_kernel"), ("c5", 5, r"pipe_tick_kernel"),
              ("wave8192", None, r"chain_wave_kernel")]
