@@ -209,7 +209,8 @@ def main():
                     help="skip the untimed run-to-convergence (profiling: only the timed launches reach the profiler)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of configs 3-5")
     ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic role ablation (invalid results)")
-    ap.add_argument("--inflight", type=int, default=2, help="analyses in flight on this rank (the plan's two result slots); 1 = one after the other")
+    ap.add_argument("--streams", type=int, default=2, help="plans on streams of their own whose analyses overlap on the chip; 1 = one stream")
+    ap.add_argument("--inflight", type=int, default=2, help="result slots used per plan (analyses of one plan in flight); 1 = fetch before the next launch")
     ap.add_argument("--dump", default="", help="rank 0: write the gathered arrays of the last launch to this .npz (tests)")
     args = ap.parse_args()
 
@@ -268,10 +269,20 @@ def main():
                              waves_per_chain=args.waves, exec_mode=args.mode, debug_flags=args.debug_flags)
         plan = engine.Plan(setup, q, I, sigma, st)
     # Analyses in flight: every launch is a complete analyse() of this rank's repetitions whose results come back to the host.
-    # The plan has two RESULT SLOTS over one set of workspaces (mcsas_hip_plan_launch_slot): the next analysis is already queued
-    # on the stream while the previous one's results are fetched and unpacked, so the GPU does not idle for the host (a series
-    # of data sets, mcsas_amd.run_series, is the use case).  --inflight 1: strictly one after the other.
+    #  * --streams S (default 2): S plans, each on a stream of its own.  Their tick kernels share the chip: an analysis' first
+    #    ~45 ticks are bound by its scan blocks (50 of 256 CUs busy for twice as long as the producers), its last ~60 by the
+    #    producers — two analyses at different stages fill each other's idle CUs (3.2e8 against 2.9e8 steps/s on one stream).
+    #  * --inflight (default 2): result slots per plan (mcsas_hip_plan_launch_slot) — the plan's next analysis is already queued
+    #    while the previous one's results are fetched and unpacked.
+    # A series of data sets (mcsas_amd.run_series; the reference's gui/calc.py:271-330 runs them one after the other) is the use
+    # case.  --streams 1 --inflight 1: strictly one analysis after the other.
     nslots = 1 if dry else max(1, min(args.inflight, 2))
+    plans = [plan]
+    streams = [None]
+    if not dry and args.streams > 1:
+        plans += [engine.Plan(setup, q, I, sigma, st) for _ in range(args.streams - 1)]
+        streams = [torch.cuda.Stream() for _ in plans]
+    lanes = [(k, sl) for sl in range(nslots) for k in range(len(plans))]      # launch order: A0 B0 A1 B1 ...
 
     launch_ms = []
     gathered = {}
@@ -279,26 +290,26 @@ def main():
     state = {"mc": 0, "res": None, "n": 0}
 
     def retire():
-        slot = pending.pop(0)
-        res = plan.fetch() if dry else plan.fetch(slot=slot)
-        launch_ms.append(plan.last_ms)
-        state["mc"] += plan.total_steps
+        k, slot = pending.pop(0)
+        pl = plans[k]
+        res = pl.fetch() if dry else pl.fetch(slot=slot)
+        launch_ms.append(pl.last_ms)
+        state["mc"] += pl.total_steps
         state["res"] = res
         return res
 
     def one_launch(seed):
-        slot = state["n"] % nslots
+        k, slot = lanes[state["n"] % len(lanes)]
         state["n"] += 1
-        while slot in pending:                            # (its previous analysis must be home before the slot is written again)
+        while (k, slot) in pending or len(pending) >= len(lanes):   # (a slot's previous analysis must be home before it is written again)
             retire()
-        plan.reseed(seed, first)
+        pl = plans[k]
+        pl.reseed(seed, first)
         if dry:
-            plan.launch()
+            pl.launch()
         else:
-            plan.launch(slot=slot)
-        pending.append(slot)
-        while len(pending) >= nslots:
-            retire()
+            pl.launch(stream=streams[k].cuda_stream if streams[k] is not None else None, slot=slot)
+        pending.append((k, slot))
 
     def drain():
         while pending:
@@ -335,6 +346,7 @@ def main():
     drain()
     barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     mc_total, res = state["mc"], state["res"]
     gather_last()
     ranks_seen = 1
@@ -351,7 +363,10 @@ def main():
         if args.dump:
             np.savez(args.dump, **gathered)
         lm = np.array(launch_ms) if launch_ms else np.zeros(1)
-        launch_s = float(lm.mean()) * 1e-3
+        # device time of one analysis: its HIP-event time on its stream — or, with several streams whose kernels share the chip
+        # (an analysis' events then bracket the other analyses' kernels too), this rank's timed region / its analyses
+        overlapped = len(plans) > 1
+        launch_s = (dt_local / max(len(launch_ms), 1)) if overlapped else float(lm.mean()) * 1e-3
         steps_per_launch = mc_total / max(len(launch_ms), 1)
         nq = len(q)
         achieved = 40 * nq * steps_per_launch / max(launch_s, 1e-12)
@@ -365,10 +380,13 @@ def main():
             "config": {"workload": "%s, %d reps on this rank (%d in all), %d MC steps per chain per launch, convergenceCriterion=0"
                                    % (wl["name"], reps, n_total, mc_steps),
                        "baseline_config": args.config, "reps_total": n_total, "launches_per_step": lps,
-                       "ranks_seen": ranks_seen, **info},
+                       "ranks_seen": ranks_seen, "streams": len(plans), "result_slots": nslots, **info},
             "timed_region_s": dt,
             "launch_ms": {"n": int(len(lm)), "min": float(lm.min()), "median": float(np.median(lm)), "max": float(lm.max()),
-                          "mean": float(lm.mean())},
+                          "mean": float(lm.mean()),
+                          "note": "HIP events around each analysis on its stream" + ("; %d streams share the chip, so an analysis' events "
+                                  "span the other streams' kernels as well: effective_ms is the timed region / analyses" % len(plans) if overlapped else "")},
+            "launch_ms_effective": launch_s * 1e3,
         }
         if not dry:
             out["final_chisq_median"] = float(np.median(res.chisq))
