@@ -19,7 +19,10 @@ repetition index either way; nothing in an analysis needs another rank (no data-
 after the timed region puts the last analysis together.
 
 Prints ONE JSON line (rank 0); besides the contract's keys: `roofline` (the SURVEY 8d byte model — 40 Q bytes per MC step —
-against the HBM peak, with the memory-side traffic of the committed FETCH/WRITE passes as `traffic`), `roofline_valu` (the
+against the HBM peak for the tick kernels of ONE analysis by themselves: HIP-event time of analyses run alone on one stream,
+`launch_ms_solo`; with the memory-side traffic of the committed FETCH/WRITE passes as `traffic`), `launch_ms` /
+`launch_ms_effective` (per-analysis event times in the timed region, where two streams share the chip, and the timed region
+divided by its analyses), `roofline_valu` (the
 resource the counters name for these kernels: fp64 vector issue), `launch_ms` (min / median / max), `configs`
 (configs 3-5 at their per-GPU repetition counts, each sustained over >= 1 s of back-to-back launches),
 `convergence_run` (criterion 1 as BASELINE names it), `quickstart` (the reference's published workload end to end) and
@@ -349,6 +352,15 @@ def main():
     dt_local = dt
     mc_total, res = state["mc"], state["res"]
     gather_last()
+    # The dominant kernel by itself, for the roofline objects: with several streams an analysis' HIP events bracket the other
+    # streams' kernels too, so a few analyses are run ALONE on one stream behind the timed region and their event times taken
+    # (that is also what the committed rocprofv3 passes characterise: tools/profile_r03.sh runs --streams 1 --inflight 1).
+    solo_ms = []
+    if not dry and len(plans) > 1:
+        for i in range(8):
+            plan.reseed(seed + i, first); plan.launch(); plan.fetch(want_arrays=False)
+            if i >= 2:
+                solo_ms.append(plan.last_ms)
     ranks_seen = 1
     if use_dist:
         dev = "cuda" if backend == "nccl" and not dry else "cpu"
@@ -366,7 +378,8 @@ def main():
         # device time of one analysis: its HIP-event time on its stream — or, with several streams whose kernels share the chip
         # (an analysis' events then bracket the other analyses' kernels too), this rank's timed region / its analyses
         overlapped = len(plans) > 1
-        launch_s = (dt_local / max(len(launch_ms), 1)) if overlapped else float(lm.mean()) * 1e-3
+        launch_eff_s = (dt_local / max(len(launch_ms), 1)) if overlapped else float(lm.mean()) * 1e-3
+        launch_s = float(np.mean(solo_ms)) * 1e-3 if solo_ms else float(lm.mean()) * 1e-3     # one analysis alone on the chip
         steps_per_launch = mc_total / max(len(launch_ms), 1)
         nq = len(q)
         achieved = 40 * nq * steps_per_launch / max(launch_s, 1e-12)
@@ -386,7 +399,9 @@ def main():
                           "mean": float(lm.mean()),
                           "note": "HIP events around each analysis on its stream" + ("; %d streams share the chip, so an analysis' events "
                                   "span the other streams' kernels as well: effective_ms is the timed region / analyses" % len(plans) if overlapped else "")},
-            "launch_ms_effective": launch_s * 1e3,
+            "launch_ms_effective": launch_eff_s * 1e3,
+            "launch_ms_solo": {"n": len(solo_ms), "mean": float(np.mean(solo_ms)), "min": float(np.min(solo_ms)), "max": float(np.max(solo_ms)),
+                               "note": "analyses run alone on one stream behind the timed region: the kernel time the roofline objects use"} if solo_ms else None,
         }
         if not dry:
             out["final_chisq_median"] = float(np.median(res.chisq))

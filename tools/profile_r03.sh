@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/r03prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline --no-convergence-run --no-configs --launches-per-step 1"
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-convergence-run --no-configs --launches-per-step 1 --streams 1 --inflight 1"   # one analysis at a time: the kernels by themselves
 SQ1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY"
 SQ2="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM"
 run() { # tag, extra bench args
