@@ -279,6 +279,9 @@ int mcsas_hip_rebin(int32_t n, const double *x, const double *f, const double *f
 int         mcsas_hip_plugin_compile(const char *source, int32_t *model_id);
 const char *mcsas_hip_plugin_log(void);
 
+/* Device and pinned memory that destroyed plans gave back stays parked for the next plan of the same shape (a series of
+ * analyses pays ~3 ms per plan in hipFree / hipHostFree otherwise), up to 4 GiB per process; this returns it to the driver. */
+int         mcsas_hip_release_cached_memory(void);
 int         mcsas_hip_device_count(void);
 int         mcsas_hip_abi_version(void);
 /* 0: the release library.  1: a measurement build (-DMCSAS_TUNING) in which mcsas_problem.reserved0 selects tuning and

@@ -26,7 +26,7 @@ SYMBOLS = (
     "mcsas_hip_plan_last_ms", "mcsas_hip_plan_total_steps", "mcsas_hip_plan_reseed", "mcsas_hip_plan_info",
     "mcsas_hip_plan_destroy", "mcsas_hip_model_calc", "mcsas_hip_bgfit", "mcsas_hip_observability",
     "mcsas_hip_histogram_prep", "mcsas_hip_prepare_uncertainty", "mcsas_hip_rebin",
-    "mcsas_hip_plugin_compile", "mcsas_hip_plugin_log",
+    "mcsas_hip_plugin_compile", "mcsas_hip_plugin_log", "mcsas_hip_release_cached_memory",
     "mcsas_hip_device_count", "mcsas_hip_abi_version", "mcsas_hip_is_tuning_build", "mcsas_hip_last_error",
 )
 

@@ -430,9 +430,87 @@ struct DeviceGuard {
 // proposals, ~3 MB at config 2 — is carved out of 8 MB chunks, 256-byte aligned: a tick's blocks each touch a dozen of
 // these small arrays before their first row, and packed into one 2 MB-aligned range they share a handful of page-table
 // entries instead of one scattered 4 KB / 64 KB page per array (and a plan costs 6 hipMalloc calls instead of 25).
+// Memory that plans give back is kept for the next plan (per device, exact size): a series of analyses — McSAS.calc() per data
+// set, one plan each — otherwise pays ~3 ms of hipFree / hipHostFree per plan for 3.4 ms of kernels, plus as much for stream and
+// pinned-memory creation.  Up to MCSAS_CACHE_BYTES of device memory stay parked; mcsas_hip_release_cached_memory() frees them.
+struct MemCache {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void *> dev;        // (device, bytes) -> free device blocks
+    std::multimap<std::pair<unsigned, size_t>, void *> host;  // (flags, bytes) -> free pinned blocks
+    std::map<int, hipStream_t> copy_stream;                   // per device: the non-blocking stream results come back on
+    size_t dev_bytes = 0;
+    static constexpr size_t MCSAS_CACHE_BYTES = (size_t)4 << 30;
+};
+static MemCache &mem_cache() { static MemCache c; return c; }
+static hipError_t cached_dev_malloc(void **p, size_t n) {
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return e;
+    {
+        MemCache &c = mem_cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.dev.find({d, n});
+        if (it != c.dev.end()) { *p = it->second; c.dev.erase(it); c.dev_bytes -= n; return hipSuccess; }
+    }
+    e = hipMalloc(p, n);
+    if (e == hipErrorOutOfMemory) {                           // parked blocks of other sizes may be in the way
+        { MemCache &c = mem_cache(); std::lock_guard<std::mutex> lk(c.mu); for (auto &kv : c.dev) hipFree(kv.second); c.dev.clear(); c.dev_bytes = 0; }
+        (void)hipGetLastError();
+        e = hipMalloc(p, n);
+    }
+    return e;
+}
+static void cached_dev_free(void *p, size_t n, int d) {
+    MemCache &c = mem_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.dev_bytes + n <= MemCache::MCSAS_CACHE_BYTES) { c.dev.insert({{d, n}, p}); c.dev_bytes += n; }
+    else hipFree(p);
+}
+static hipError_t cached_host_malloc(void **p, size_t n, unsigned flags) {
+    {
+        MemCache &c = mem_cache();
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.host.find({flags, n});
+        if (it != c.host.end()) { *p = it->second; c.host.erase(it); return hipSuccess; }
+    }
+    return hipHostMalloc(p, n, flags);
+}
+static void cached_host_free(void *p, size_t n, unsigned flags) {
+    if (!p) return;
+    MemCache &c = mem_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (c.host.size() < 64) c.host.insert({{flags, n}, p});
+    else hipHostFree(p);
+}
+static hipError_t cached_copy_stream(hipStream_t *st) {
+    int d = 0;
+    hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) return e;
+    MemCache &c = mem_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.copy_stream.find(d);
+    if (it == c.copy_stream.end()) {
+        hipStream_t s = nullptr;
+        e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        it = c.copy_stream.emplace(d, s).first;
+    }
+    *st = it->second;
+    return hipSuccess;
+}
+extern "C" int mcsas_hip_release_cached_memory(void) {
+    MemCache &c = mem_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (auto &kv : c.dev) hipFree(kv.second);
+    for (auto &kv : c.host) hipHostFree(kv.second);
+    c.dev.clear(); c.host.clear(); c.dev_bytes = 0;
+    return MCSAS_OK;
+}
+
 struct DevPool {
     static constexpr size_t CHUNK = (size_t)8 << 20, BIG = (size_t)2 << 20, ALIGN = 256;
-    std::vector<void *> blocks;         // everything to hipFree
+    std::vector<std::pair<void *, size_t>> blocks;   // everything to give back
+    int dev = 0;
     char *cur = nullptr;
     size_t left = 0;
     hipError_t get(void **out, size_t n) {
@@ -440,22 +518,23 @@ struct DevPool {
         n = (n ? n : 1);
         n = (n + ALIGN - 1) / ALIGN * ALIGN;
         void *p = nullptr;
+        if (blocks.empty()) (void)hipGetDevice(&dev);
         if (n >= BIG) {
-            hipError_t e = hipMalloc(&p, n);
+            hipError_t e = cached_dev_malloc(&p, n);
             if (e != hipSuccess) return e;
-            blocks.push_back(p); *out = p;
+            blocks.push_back({p, n}); *out = p;
             return hipSuccess;
         }
         if (n > left) {                 // (the tail of the old chunk stays unused)
-            hipError_t e = hipMalloc(&p, CHUNK);
+            hipError_t e = cached_dev_malloc(&p, CHUNK);
             if (e != hipSuccess) return e;
-            blocks.push_back(p); cur = (char *)p; left = CHUNK;
+            blocks.push_back({p, (size_t)CHUNK}); cur = (char *)p; left = CHUNK;
         }
         *out = cur; cur += n; left -= n;
         return hipSuccess;
     }
     template <class T> hipError_t get(T **out, size_t n_bytes) { return get((void **)out, n_bytes); }
-    void release() { for (void *b : blocks) hipFree(b); blocks.clear(); cur = nullptr; left = 0; }
+    void release() { for (auto &b : blocks) cached_dev_free(b.first, b.second, dev); blocks.clear(); cur = nullptr; left = 0; }
 };
 
 struct mcsas_plan {
@@ -530,7 +609,7 @@ static int plan_activate_slot(mcsas_plan *pl, int k) {
         HIPCHK(hipMemset(n.d_out, 0, sizeof(ChainOut) * R));
         HIPCHK(hipEventCreate(&n.ev0)); HIPCHK(hipEventCreate(&n.ev1));
         if (pl->mode == MCSAS_EXEC_PIPELINE) {
-            HIPCHK(hipHostMalloc((void **)&n.h_done, sizeof(int32_t), hipHostMallocMapped));
+            HIPCHK(cached_host_malloc((void **)&n.h_done, sizeof(int32_t), hipHostMallocMapped));
             *n.h_done = 0;
             HIPCHK(hipHostGetDevicePointer((void **)&n.d_done_map, n.h_done, 0));
         }
@@ -586,11 +665,14 @@ static void *wg_kernel_for(int model, int qpl) {
 
 extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     if (!pl) return;
+    // (nothing of this plan may still be running when its memory goes back to the cache: hipFree used to wait, the cache does not)
+    if (pl->launched && pl->ev1) (void)hipEventSynchronize(pl->ev1);
+    for (int k = 0; k < MCSAS_PLAN_SLOTS; ++k)
+        if (k != pl->cur_slot && pl->slots[k].made && pl->slots[k].launched && pl->slots[k].ev1) (void)hipEventSynchronize(pl->slots[k].ev1);
     pl->pool.release();                 // every device array of the plan
-    if (pl->h_stop) hipHostFree(pl->h_stop);
-    if (pl->h_done) hipHostFree(pl->h_done);
-    if (pl->h_pipeargs) hipHostFree(pl->h_pipeargs);
-    if (pl->sCopy) hipStreamDestroy(pl->sCopy);
+    cached_host_free(pl->h_stop, sizeof(int32_t), hipHostMallocMapped);
+    cached_host_free(pl->h_done, sizeof(int32_t), hipHostMallocMapped);
+    cached_host_free(pl->h_pipeargs, sizeof(PipeArgs), hipHostMallocDefault);
     for (int i = 0; i < mcsas_plan::RING; ++i) {
         if (pl->evP[i]) hipEventDestroy(pl->evP[i]);
         if (pl->evS[i]) hipEventDestroy(pl->evS[i]);
@@ -602,8 +684,8 @@ extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     for (int k = 0; k < MCSAS_PLAN_SLOTS; ++k) {          // the parked result slots (the active one's members were freed above)
         if (k == pl->cur_slot || !pl->slots[k].made) continue;
         mcsas_plan::Slot &sl = pl->slots[k];
-        if (sl.h_done) hipHostFree(sl.h_done);
-        if (sl.h_pipeargs) hipHostFree(sl.h_pipeargs);
+        cached_host_free(sl.h_done, sizeof(int32_t), hipHostMallocMapped);
+        cached_host_free(sl.h_pipeargs, sizeof(PipeArgs), hipHostMallocDefault);
         if (sl.ev0) hipEventDestroy(sl.ev0);
         if (sl.ev1) hipEventDestroy(sl.ev1);
     }
@@ -813,7 +895,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         PCHK(pl->pool.get(&pl->d_replay, rb));
         PCHK(hipMemcpy(pl->d_replay, p->replay_stream, rb, hipMemcpyHostToDevice));
     }
-    PCHK(hipHostMalloc((void **)&pl->h_stop, sizeof(int32_t), hipHostMallocMapped));
+    PCHK(cached_host_malloc((void **)&pl->h_stop, sizeof(int32_t), hipHostMallocMapped));
     *pl->h_stop = 0;
     int32_t *d_stop = nullptr;
     PCHK(hipHostGetDevicePointer((void **)&d_stop, pl->h_stop, 0));
@@ -879,7 +961,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         PCHK(pl->pool.get(&pl->d_pval, sizeof(double) * R * 2 * Kb * MCSAS_MAX_ACTIVE));
         PCHK(pl->pool.get(&pl->d_povf, sizeof(int32_t) * R * 2 * Kb));
         PCHK(hipMemset(pl->d_povf, 0, sizeof(int32_t) * R * 2 * Kb));
-        PCHK(hipHostMalloc((void **)&pl->h_done, sizeof(int32_t), hipHostMallocMapped));
+        PCHK(cached_host_malloc((void **)&pl->h_done, sizeof(int32_t), hipHostMallocMapped));
         *pl->h_done = 0;
         int32_t *d_done = nullptr;
         PCHK(hipHostGetDevicePointer((void **)&d_done, pl->h_done, 0));
@@ -926,7 +1008,7 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     *pl->h_done = 0;
     HIPCHK(hipMemsetAsync(pl->d_done_dev, 0, sizeof(int32_t), st));
     pa.tick = 0;
-    if (!pl->h_pipeargs) HIPCHK(hipHostMalloc((void **)&pl->h_pipeargs, sizeof(PipeArgs), hipHostMallocDefault));
+    if (!pl->h_pipeargs) HIPCHK(cached_host_malloc((void **)&pl->h_pipeargs, sizeof(PipeArgs), hipHostMallocDefault));
     *pl->h_pipeargs = pa;                                // (the previous launch's upload has completed: fetch() or the caller waited for it)
     HIPCHK(hipMemcpyAsync(pl->d_pipeargs, pl->h_pipeargs, sizeof(PipeArgs), hipMemcpyHostToDevice, st));
     HIPCHK(hipEventRecord(pl->ev0, st));
@@ -1051,7 +1133,7 @@ extern "C" int mcsas_hip_plan_fetch_slot(mcsas_plan *pl, int32_t slot, mcsas_res
         std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
     HIPCHK(hipEventSynchronize(pl->ev1));
-    if (!pl->sCopy) HIPCHK(hipStreamCreateWithFlags(&pl->sCopy, hipStreamNonBlocking));
+    if (!pl->sCopy) HIPCHK(cached_copy_stream(&pl->sCopy));      // (one per device, shared by every plan)
     // device -> host on the copy stream (the data is complete: ev1 has passed)
     auto d2h = [&](void *dst, const void *src, size_t n) -> hipError_t {
         hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, pl->sCopy);

@@ -26,6 +26,11 @@ class PluginCompileError(ValueError):
         self.log = log
 
 
+def release_cached_memory(tuning=False):
+    """Returns the device / pinned memory parked by destroyed plans to the driver (mcsas_hip_release_cached_memory)."""
+    check(_lib.load(tuning).mcsas_hip_release_cached_memory(), _lib.load(tuning))
+
+
 def compile_plugin(source: str, tuning=False) -> int:
     """Registers HIP source text for a model outside the built-in ones (mcsas_hip_plugin_compile, include/mcsas_hip.h: the
     four functions mcsas_plugin_formfactor / _volume / _absvolume / _surface) and returns its model id.  Needs no GPU; the
