@@ -1346,10 +1346,21 @@ extern "C" int mcsas_hip_analyse(const mcsas_problem *p, mcsas_result *res) {
 }
 
 // ------------------------------------------------------------------------------ model.calc
+// scratch arrays of the one-call entry points below: from / back to the process-level cache (a histogram() makes a dozen of them)
 template <typename T> struct DevBuf {
     T *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, sizeof(T) * (n ? n : 1)); }
+    size_t bytes = 0;
+    int dev = 0;
+    ~DevBuf() {
+        if (!p) return;
+        (void)hipDeviceSynchronize();              // (hipFree used to wait for the kernels that read it; the cache does not)
+        cached_dev_free(p, bytes, dev);
+    }
+    hipError_t alloc(size_t n) {
+        bytes = (sizeof(T) * (n ? n : 1) + 255) / 256 * 256;
+        (void)hipGetDevice(&dev);
+        return cached_dev_malloc((void **)&p, bytes);
+    }
 };
 
 extern "C" int mcsas_hip_model_calc(const mcsas_problem *p, const double *pset, int32_t n, double *cum_int,
