@@ -494,24 +494,59 @@ def other_configs(dev_index, seconds=1.0):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         info = plan.info
-        plan.close()
         rate = steps / dt
+        # ... and the same with a second plan on a stream of its own, two result slots each (the main workload's scheme): the
+        # analyses fill each other's tails — a tick of these kernels ends with its slowest row, and 13 Kholodenko chains load the
+        # chip in one uneven round
+        plan_b = engine.Plan(setup, wl["q"], wl["I"], wl["sigma"], st)
+        pls, sts = [plan, plan_b], [torch.cuda.Stream(), torch.cuda.Stream()]
+        lanes2 = [(k, sl) for sl in range(2) for k in range(2)]
+        pend, steps2, n2 = [], 0, 0
+
+        def retire2():
+            k, sl = pend.pop(0)
+            pls[k].fetch(slot=sl)
+            return pls[k].total_steps
+
+        for i in range(4):                                    # warm-up: every slot once
+            k, sl = lanes2[i]
+            pls[k].reseed(300 + i, 0); pls[k].launch(stream=sts[k].cuda_stream, slot=sl); pend.append((k, sl))
+        while pend:
+            retire2()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while True:
+            k, sl = lanes2[n2 % 4]
+            while (k, sl) in pend or len(pend) >= 4:
+                steps2 += retire2()
+            pls[k].reseed(400 + n2, 0); pls[k].launch(stream=sts[k].cuda_stream, slot=sl); pend.append((k, sl)); n2 += 1
+            if time.perf_counter() - t0 >= seconds:
+                break
+        while pend:
+            steps2 += retire2()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t0
+        plan.close(); plan_b.close()
+        rate_one, rate = rate, steps2 / dt2
         dev_s = float(np.sum(ms)) * 1e-3
         nq = len(wl["q"])
         pts = nq * wl["K"]                                    # form-factor points evaluated per MC step: the `new` row (`old` comes from the row cache)
         e = {"workload": "%s, %d reps (per-GPU share of %d), %d MC steps per chain per launch" % (wl["name"], wl["reps_gpu"], wl["reps_total"], budget),
-             "value": rate, "unit": "MC steps/s", "timed_region_s": dt, "launches": n, "mc_steps": steps,
-             "launch_ms": {"min": float(np.min(ms)), "median": float(np.median(ms)), "max": float(np.max(ms))},
-             "init_ms": init, "value_excl_init": steps / max(dev_s - n * init * 1e-3, 1e-9),
+             "value": rate, "unit": "MC steps/s", "timed_region_s": dt2, "launches": n2, "mc_steps": steps2,
+             "streams": 2, "result_slots": 2,
+             "one_stream": {"value": rate_one, "timed_region_s": dt, "launches": n, "mc_steps": steps,
+                            "launch_ms": {"min": float(np.min(ms)), "median": float(np.median(ms)), "max": float(np.max(ms))},
+                            "init_ms": init, "value_excl_init": steps / max(dev_s - n * init * 1e-3, 1e-9)},
              "exec_mode": info["exec_mode"], "window": info["window"], "final_chisq_median": float(np.median(res.chisq)),
              "ff_points_per_s": rate * pts, "ff_points_per_mc_step": pts}
-        alg = {"bound": "hbm", "achieved": 40 * nq * rate / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 40 * nq * rate / HBM_PEAK}
+        # (roofline objects: the kernels of one analysis by themselves, like the main workload's)
+        alg = {"bound": "hbm", "achieved": 40 * nq * rate_one / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 40 * nq * rate_one / HBM_PEAK}
         pv = prof.get(str(cfg))
         tr = traf.get(str(cfg))
-        traffic = (tr["fetch_bytes_per_mc_step"] + tr["write_bytes_per_mc_step"]) * rate / 1e9 if tr else None
+        traffic = (tr["fetch_bytes_per_mc_step"] + tr["write_bytes_per_mc_step"]) * rate_one / 1e9 if tr else None
         e["roofline"] = dict(alg, traffic=traffic, traffic_unit="GB/s")
         if pv:
-            r = pv["valu_wave_instr_per_mc_step"] * rate
+            r = pv["valu_wave_instr_per_mc_step"] * rate_one
             e["roofline_valu"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
                                   "frac": r / FP64_VECTOR_PEAK_INSTR, "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
                                   "source": "from_profile: profiles/r03_valu_per_step.json / r03_pmc_traffic.json (commit %s)" % pv.get("commit", "?")}
