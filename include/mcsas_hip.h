@@ -279,6 +279,10 @@ int mcsas_hip_rebin(int32_t n, const double *x, const double *f, const double *f
 int         mcsas_hip_plugin_compile(const char *source, int32_t *model_id);
 const char *mcsas_hip_plugin_log(void);
 
+/* A (non-blocking) HIP stream on `device` for mcsas_hip_plan_launch, for hosts that have no HIP binding of their own: plans on
+ * different streams overlap on the chip — two analyses side by side finish sooner than one after the other. */
+int         mcsas_hip_stream_create(int32_t device, void **stream);
+void        mcsas_hip_stream_destroy(void *stream);
 /* Device and pinned memory that destroyed plans gave back stays parked for the next plan of the same shape (a series of
  * analyses pays ~3 ms per plan in hipFree / hipHostFree otherwise), up to 4 GiB per process; this returns it to the driver. */
 int         mcsas_hip_release_cached_memory(void);

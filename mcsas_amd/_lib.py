@@ -26,7 +26,7 @@ SYMBOLS = (
     "mcsas_hip_plan_last_ms", "mcsas_hip_plan_total_steps", "mcsas_hip_plan_reseed", "mcsas_hip_plan_info",
     "mcsas_hip_plan_destroy", "mcsas_hip_model_calc", "mcsas_hip_bgfit", "mcsas_hip_observability",
     "mcsas_hip_histogram_prep", "mcsas_hip_prepare_uncertainty", "mcsas_hip_rebin",
-    "mcsas_hip_plugin_compile", "mcsas_hip_plugin_log", "mcsas_hip_release_cached_memory",
+    "mcsas_hip_plugin_compile", "mcsas_hip_plugin_log", "mcsas_hip_release_cached_memory", "mcsas_hip_stream_create", "mcsas_hip_stream_destroy",
     "mcsas_hip_device_count", "mcsas_hip_abi_version", "mcsas_hip_is_tuning_build", "mcsas_hip_last_error",
 )
 
@@ -127,6 +127,9 @@ def load(tuning=False):
     lib.mcsas_hip_prepare_uncertainty.argtypes = [C.c_int32, _dp, _dp, C.c_double, C.c_int32, _dp]
     lib.mcsas_hip_rebin.argtypes = [C.c_int32, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp, _i32p]
     lib.mcsas_hip_plugin_compile.argtypes = [C.c_char_p, _i32p]
+    lib.mcsas_hip_stream_create.argtypes = [C.c_int32, C.POINTER(C.c_void_p)]
+    lib.mcsas_hip_stream_destroy.argtypes = [C.c_void_p]
+    lib.mcsas_hip_stream_destroy.restype = None
     lib.mcsas_hip_plugin_log.restype = C.c_char_p
     _libs[key] = lib
     return lib

@@ -1561,6 +1561,21 @@ extern "C" int mcsas_hip_rebin(int32_t n, const double *x, const double *f, cons
     return MCSAS_OK;
 }
 
+// streams for hosts without a HIP binding of their own (ctypes / cgo callers that want analyses on several streams)
+extern "C" int mcsas_hip_stream_create(int32_t device, void **stream) {
+    if (!stream) return fail(MCSAS_EINVAL, "null argument");
+    DeviceGuard dev_guard;
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = (void *)st;
+    return MCSAS_OK;
+}
+extern "C" void mcsas_hip_stream_destroy(void *stream) {
+    if (stream) (void)hipStreamDestroy((hipStream_t)stream);
+}
+
 extern "C" int mcsas_hip_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

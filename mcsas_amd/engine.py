@@ -193,6 +193,41 @@ def analyse(model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, s
     return res
 
 
+def analyse_many(problems, streams=2):
+    """Independent analyses — a series of data sets (gui/calc.py:271-330 runs them one after the other) — side by side: every
+    problem gets a plan of its own (creation is cheap: the library keeps destroyed plans' memory), the plans go round `streams`
+    HIP streams, two per stream in flight, so the chip always has one analysis' scan-bound ticks beside another's producer-bound
+    ones.  `problems`: sequence of (model: ModelSetup, q, intensity, sigma, settings) or of dicts with those keys
+    plus optional replay / stop / smear.  Returns the ChainResults in order — each identical to analyse() of that problem."""
+    problems = [p if isinstance(p, dict) else dict(model=p[0], q=p[1], intensity=p[2], sigma=p[3], st=p[4]) for p in problems]
+    if not problems:
+        return []
+    lib = _lib.load(tuning=bool(problems[0]["st"].debug_flags))
+    hs = []
+    for _ in range(max(1, min(streams, len(problems)))):
+        h = C.c_void_p()
+        check(lib.mcsas_hip_stream_create(C.c_int32(problems[0]["st"].device), C.byref(h)), lib)
+        hs.append(h)
+    out, pending = [None] * len(problems), []
+    try:
+        for i, pr in enumerate(problems):
+            while len(pending) >= 2 * len(hs):
+                j, pl = pending.pop(0)
+                out[j] = pl.fetch(); pl.close()
+            pl = Plan(pr["model"], pr["q"], pr["intensity"], pr["sigma"], pr["st"], pr.get("replay"), pr.get("stop"), pr.get("smear"))
+            pl.launch(stream=hs[i % len(hs)].value)
+            pending.append((i, pl))
+        while pending:
+            j, pl = pending.pop(0)
+            out[j] = pl.fetch(); pl.close()
+    finally:
+        for _, pl in pending:
+            pl.close()
+        for h in hs:
+            lib.mcsas_hip_stream_destroy(h)
+    return out
+
+
 class Plan:
     """Resident plan: data and workspaces stay in HBM; launch/fetch can be repeated (bench.py)."""
 

@@ -115,11 +115,28 @@ class McSAS(object):
             numContribs, numReps = 1, 1                      # mcsas.py:198-199: nothing active, nothing to fit
         else:
             numContribs, numReps = self.numContribs(), self.numReps()
-        st = self._settings(numContribs, numReps)
-        setup = setup_from_model(model, data)
+        pr = self._problem(numContribs, numReps, replay)
+        res = engine.analyse(pr["model"], pr["q"], pr["intensity"], pr["sigma"], pr["st"],
+                             replay=pr["replay"], stop=pr["stop"], smear=pr["smear"])
+        self._store(res, numReps)
+
+    def _problem(self, numContribs=None, numReps=None, replay=None):
+        """What analyse() hands to the library for the current data / model / settings (engine.analyse_many takes a list of these)."""
+        data, model = self.data, self.model
+        if numContribs is None:
+            active = any(isActiveFitParam(p) for p in model.params())
+            numContribs, numReps = (self.numContribs(), self.numReps()) if active else (1, 1)
         smear = data.smearArgs(model) if hasattr(data, "smearArgs") else None   # sasmodel.py:56-60
-        res = engine.analyse(setup, data.q, data.f.binnedData, data.f.binnedDataU, st,
-                             replay=replay, stop=self._stop, smear=smear)
+        return dict(model=setup_from_model(model, data), q=data.q, intensity=data.f.binnedData, sigma=data.f.binnedDataU,
+                    st=self._settings(numContribs, numReps), replay=replay, stop=self._stop, smear=smear)
+
+    def _store(self, res, numReps=None):
+        """The second half of analyse() (mcsas.py:221-285): warnings, active values, the result dictionary."""
+        data, model = self.data, self.model
+        if self.result is None:
+            self.result = []
+        if numReps is None:
+            numReps = res.contribs.shape[2]
         self.details = res
         if (res.converged == 0).any():                       # mcsas.py:221-230 / :240-245
             if self.stop:

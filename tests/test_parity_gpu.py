@@ -1234,3 +1234,45 @@ def test_result_slots_keep_two_analyses_apart(mode):
             np.testing.assert_array_equal(getattr(got, name), getattr(alone[seed], name), err_msg="%s seed %d" % (name, seed))
     with pytest.raises(mcsas_amd._lib.McSASHipError):
         pl.launch(slot=2)
+
+
+def test_analyse_many_and_overlapped_series_equal_one_after_the_other():
+    """engine.analyse_many — a plan per problem, the plans going round two streams, analyses side by side on the chip — returns what
+    analyse() returns for each problem (different models, shapes and modes in one list); run_series(overlap=True) gives the same
+    results and the same series table as the data sets one after the other."""
+    probs = []
+    for nq, tag, n, reps, steps, mode in ((100, "sphere", 120, 5, 900, engine.EXEC_AUTO), (257, "gausschain", 60, 3, 400, engine.EXEC_WAVE),
+                                          (64, "cyl_aspect", 48, 4, 150, engine.EXEC_PIPELINE), (1500, "sphere", 40, 2, 120, engine.EXEC_AUTO),
+                                          (100, "sphere", 120, 5, 900, engine.EXEC_WORKGROUP)):
+        q, I, sig = _synthetic(nq)
+        lo, hi = RANDOM_RANGES[tag]
+        m, _ = make_models(tag, lo, hi, **({"intDiv": 20.} if tag == "cyl_aspect" else {}))
+        st = engine.Settings(n_contrib=n, n_reps=reps, max_iter=steps, conv_crit=1e-9, max_retries=0, seed=31 + nq, exec_mode=mode)
+        probs.append((m.setup(), q, I, sig, st))
+    many = engine.analyse_many(probs)
+    for pr, got in zip(probs, many):
+        one = engine.analyse(*pr)
+        for name in ("contribs", "fit", "chisq", "num_iter", "num_moves"):
+            np.testing.assert_array_equal(getattr(got, name), getattr(one, name), err_msg=name)
+    # the series driver
+    out = []
+    for overlap in (False, True):
+        datasets = []
+        for k, scale in enumerate((1.0, 0.6, 1.7)):
+            q, I, sig = _synthetic(100)
+            datasets.append(mcsas_amd.SASData(q, I * scale + k * 1e-3 * I.max(), sig * scale))
+        q = datasets[0].q
+        m = mcsas_amd.Sphere(); m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
+        m.radius.histograms().append(mcsas_amd.Histogram(m.radius, np.pi / q.max(), np.pi / q.min(), binCount=12, xscale='log', yweight='vol'))
+        algo = mcsas_amd.McSAS(seed=9)
+        algo.numContribs.setValue(80); algo.numReps.setValue(4); algo.maxIterations.setValue(1500)
+        algo.convergenceCriterion.setValue(1e-9); algo.maxRetries.setValue(1); algo.showIncomplete.setValue(True)
+        algo.model = m
+        out.append(mcsas_amd.run_series(algo, datasets, keys=[1.0, 2.0, 3.0], overlap=overlap))
+    (ra, sa), (rb, sb) = out
+    for a, b in zip(ra, rb):
+        assert np.array_equal(a["contribs"], b["contribs"]) and np.array_equal(a["fitMeasValMean"], b["fitMeasValMean"])
+    assert list(sa) == list(sb)
+    for uid in sa:
+        for (ka, ma), (kb, mb) in zip(sa[uid], sb[uid]):
+            assert ka == kb and np.array_equal(np.array(ma, dtype=float), np.array(mb, dtype=float))
