@@ -1353,7 +1353,7 @@ template <typename T> struct DevBuf {
     int dev = 0;
     ~DevBuf() {
         if (!p) return;
-        (void)hipDeviceSynchronize();              // (hipFree used to wait for the kernels that read it; the cache does not)
+        (void)hipStreamSynchronize(nullptr);       // (hipFree used to wait for the kernels that read it — they run on the null stream —; the cache does not)
         cached_dev_free(p, bytes, dev);
     }
     hipError_t alloc(size_t n) {
