@@ -16,4 +16,4 @@ for k, run in enumerate(runs[-4:]):
     d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in run]
     span = (int(run[-1]["End_Timestamp"]) - int(run[0]["Start_Timestamp"])) / 1e3
     print("analysis %d: %d ticks, sum %.1f us, first start to last end %.1f us" % (k, len(d), sum(d), span))
-    print(" ".join("%.0f" % x for x in d[:40]))
+    print(" ".join("%.1f" % x for x in d))
