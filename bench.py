@@ -10,6 +10,10 @@ min / median / max.
 
     python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--config 2|3|4|5]
 
+`value` is config 2 AS NAMED: one 50-repetition analysis on the chip at a time (one plan, one stream; the next analysis is queued
+while the previous one's results are fetched).  The throughput of a SERIES of data sets — two plans on streams of their own whose
+analyses share the chip — is reported beside it as `series_two_streams`.
+
 --gpus N > 1 without a torch.distributed environment: this process starts the N ranks itself
 (`python -m torch.distributed.run`, one process per GPU, 127.0.0.1 rendezvous) BEFORE anything touches the GPU,
 forwards their output and exits with their code; under an external launcher (WORLD_SIZE set) the world size must
@@ -64,6 +68,34 @@ def synthetic_data(nq=Q, seed=20250101):
     return q, I, sigma
 
 
+def truth_population(config, rs):
+    """"a known tri-modal population mirroring quickstart.rst:195-199 ... for the model under test".  The three
+    Gaussian modes (8 / 40 / 100 nm, widths 3 / 10 / 10 nm, 300 / 150 / 50 members) at HALF size, so that they sit inside the
+    radius ranges of configs 3 and 4 (1-100 nm); the remaining shape parameters uniform inside their ranges."""
+    r = np.abs(np.concatenate([rs.normal(4, 1.5, 300), rs.normal(20, 5, 150), rs.normal(50, 5, 50)])) + 0.5
+    r *= 1e-9
+    if config == 3:                                           # (radius, aspect)
+        return np.stack([r, rs.uniform(1.0, 8.0, len(r))], axis=1)
+    if config == 4:                                           # (a, b, t): b = a x (1..3), shell 0.5-5 nm
+        return np.stack([r, r * rs.uniform(1.0, 3.0, len(r)), rs.uniform(5e-10, 5e-9, len(r))], axis=1)
+    raise ValueError(config)
+
+
+def model_truth_data(config, model, nq, device, seed=20250101):
+    """Ground-truth I(q) of `model` for the population above, by the library's own ScatteringModel.calc (mcsas_hip_model_calc, outside
+    any timed region), normalised to a maximum of 1e3, sigma = 1 % of I, multiplicative Gaussian noise, flat background 0 — the
+    recipe of synthetic_data() with the model under test in place of the sphere."""
+    from mcsas_amd import engine
+    q = np.logspace(7, np.log10(3e9), nq)
+    rs = np.random.RandomState(seed)
+    pset = truth_population(config, rs)
+    I = engine.model_calc(model.setup(), q, pset, 0.6666666, device=device)[0]
+    I = I * (1e3 / I.max())
+    sigma = 0.01 * I
+    z = rs.normal(size=nq)
+    return q, I + sigma * z, sigma, float(np.mean(z * z))
+
+
 def kholodenko_file_data():
     """BASELINE config 5's data: testdata/sasfit_kho-1-10-1000.dat as the reference's loader prepares it (1 %
     uncertainty floor), brought to 512 q-points; the vectors are the ones the reference itself was run on for the
@@ -75,32 +107,37 @@ def kholodenko_file_data():
 
 # BASELINE.json configs 2-5: model, data, contributions, repetitions (total over 8 GPUs / per GPU), instructions
 # per form-factor point (fp64 wave-instructions per 64 points, from the SQ_INSTS_VALU passes in profiles/)
-def workload(config):
+def workload(config, device=-1, dry=False):
+    """-> dict(name, model, q, I, sigma, n, reps_total, reps_gpu, K, chisq_of_truth).  chisq_of_truth: reduced chi² of the
+    noise-free ground truth against the noisy curve (mean of the squared noise draws) — what "final chi²" is to be read against:
+    a criterion below it asks the chains to fit the noise."""
     import mcsas_amd
     if config == 2:
         q, I, s = synthetic_data(512)
+        rs = np.random.RandomState(20250101); rs.normal(size=500); z = rs.normal(size=512)     # (the draws of synthetic_data)
         m = mcsas_amd.Sphere(); m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
         return dict(name="Sphere, synthetic 512 q-points x 400 contribs", model=m, q=q, I=I, sigma=s, n=400,
-                    reps_total=50, reps_gpu=50, K=1)
+                    reps_total=50, reps_gpu=50, K=1, chisq_of_truth=float(np.mean(z * z)))
     if config == 3:
-        q, I, s = synthetic_data(512)
         m = mcsas_amd.CylindersIsotropic()
         m.radius.setActive(True); m.aspect.setActive(True)
         m.radius.setActiveRange((1e-9, 1e-7)); m.aspect.setActiveRange((0.5, 20.0))
-        return dict(name="Isotropic cylinders (radius + aspect, intDiv 100), synthetic 512 q x 400 contribs", model=m,
-                    q=q, I=I, sigma=s, n=400, reps_total=200, reps_gpu=25, K=100)
+        q, I, s, c2 = (synthetic_data(512) + (None,)) if dry else model_truth_data(3, m, 512, device)
+        return dict(name="Isotropic cylinders (radius + aspect, intDiv 100), synthetic 512 q x 400 contribs, ground truth: tri-modal "
+                         "cylinder population", model=m, q=q, I=I, sigma=s, n=400, reps_total=200, reps_gpu=25, K=100, chisq_of_truth=c2)
     if config == 4:
-        q, I, s = synthetic_data(1024)
         m = mcsas_amd.EllipsoidalCoreShell()
         for name, rng in (("a", (1e-9, 1e-7)), ("b", (2e-9, 2e-7)), ("t", (2e-10, 1e-8))):
             getattr(m, name).setActive(True); getattr(m, name).setActiveRange(rng)
-        return dict(name="Core-shell ellipsoid (a, b, t, intDiv 100), synthetic 1024 q x 1000 contribs", model=m,
-                    q=q, I=I, sigma=s, n=1000, reps_total=400, reps_gpu=50, K=200)
+        q, I, s, c2 = (synthetic_data(1024) + (None,)) if dry else model_truth_data(4, m, 1024, device)
+        return dict(name="Core-shell ellipsoid (a, b, t, intDiv 100), synthetic 1024 q x 1000 contribs, ground truth: tri-modal "
+                         "core-shell ellipsoid population", model=m, q=q, I=I, sigma=s, n=1000, reps_total=400, reps_gpu=50, K=200,
+                    chisq_of_truth=c2)
     if config == 5:
         q, I, s = kholodenko_file_data()
         m = mcsas_amd.Kholodenko()
         return dict(name="Kholodenko worm, testdata/sasfit_kho-1-10-1000.dat at 512 q x 600 contribs", model=m,
-                    q=q, I=I, sigma=s, n=600, reps_total=100, reps_gpu=13, K=1)
+                    q=q, I=I, sigma=s, n=600, reps_total=100, reps_gpu=13, K=1, chisq_of_truth=None)
     raise SystemExit("unknown --config %r" % config)
 
 
@@ -200,7 +237,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config 2..5 (headline: 2)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="default: weak for config 2 (its 50 repetitions on EVERY GPU; the strong figure — 50 in all — is reported beside "
+                         "it as `strong_scaling`), strong for configs 3-5, whose repetition counts are named as totals over 8 GPUs")
     ap.add_argument("--launches-per-step", type=int, default=0,
                     help="launches per bench step (0: enough for ~0.15 s per step on the headline config, 1 otherwise)")
     ap.add_argument("--mc-steps", type=int, default=0, help="MC iterations per chain per launch (0: 20000 for config 2)")
@@ -212,7 +251,10 @@ def main():
                     help="skip the untimed run-to-convergence (profiling: only the timed launches reach the profiler)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of configs 3-5")
     ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic role ablation (invalid results)")
-    ap.add_argument("--streams", type=int, default=2, help="plans on streams of their own whose analyses overlap on the chip; 1 = one stream")
+    ap.add_argument("--streams", type=int, default=1, help="plans on streams of their own whose analyses overlap on the chip (default 1: "
+                    "config 2 as named, one analysis on the chip at a time; the two-stream series figure is reported beside it)")
+    ap.add_argument("--no-series", action="store_true", help="skip the two-stream series measurement behind the timed region")
+    ap.add_argument("--no-many-chains", action="store_true", help="skip the wave-per-chain run (8192 chains)")
     ap.add_argument("--inflight", type=int, default=2, help="result slots used per plan (analyses of one plan in flight); 1 = fetch before the next launch")
     ap.add_argument("--dump", default="", help="rank 0: write the gathered arrays of the last launch to this .npz (tests)")
     args = ap.parse_args()
@@ -220,7 +262,10 @@ def main():
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if world_env is None and args.gpus > 1:
+    # MCSAS_BENCH_FORCE_DIST=1: the multi-rank code path — process group, RCCL all-gather of the results, all-reduce of the timings —
+    # also at world size 1 (tests/test_parity_gpu.py runs it once on the one-GPU box, so that path has executed on hardware)
+    force_dist = os.environ.get("MCSAS_BENCH_FORCE_DIST") == "1"
+    if world_env is None and (args.gpus > 1 or force_dist):
         self_launch(args, sys.argv[1:])                      # does not return
     rank = int(os.environ.get("RANK", "0")); world = int(world_env or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -243,7 +288,7 @@ def main():
             raise SystemExit("--gpus %d but only %d GPU(s) visible" % (world, ndev))
         dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
         torch.cuda.set_device(dev_index)
-    use_dist = world > 1
+    use_dist = world > 1 or force_dist
     if use_dist:
         import torch.distributed as tdist
         if backend == "nccl":
@@ -251,8 +296,10 @@ def main():
         else:
             tdist.init_process_group(backend)
 
-    wl = workload(args.config)
+    wl = workload(args.config, dev_index, dry)
     q, I, sigma, model, ncontrib = wl["q"], wl["I"], wl["sigma"], wl["model"], wl["n"]
+    if args.scaling is None:
+        args.scaling = "weak" if args.config == 2 else "strong"
     if args.scaling == "weak":
         reps = args.reps or wl["reps_gpu"]
         n_total, first = reps * world, rank * reps
@@ -290,7 +337,7 @@ def main():
     launch_ms = []
     gathered = {}
     pending = []
-    state = {"mc": 0, "res": None, "n": 0}
+    state = {"mc": 0, "res": None, "n": 0, "gather_ms": None}
 
     def retire():
         k, slot = pending.pop(0)
@@ -320,13 +367,24 @@ def main():
 
     def gather_last():
         # the ranks' blocks of the LAST analysis put together (one RCCL all-gather, outside the timed region: the repetitions
-        # are independent and nothing in an analysis needs another rank's results)
+        # are independent and nothing in an analysis needs another rank's results); timed by itself -> `gather_ms`
         res = state["res"]
         if res is not None and (use_dist or args.dump):
             local = dict(contribs=np.moveaxis(res.contribs, 2, 0), chisq=res.chisq[:, None],
                          scaling=res.scaling[:, None], background=res.background[:, None], fit=res.fit.T)
             gathered.clear()
-            gathered.update(mdist.gather_results(local, n_total) if use_dist else {k: np.asarray(v) for k, v in local.items()})
+            if use_dist:
+                ms = []
+                for _ in range(1 if dry else 3):               # (the first call pays RCCL's lazy connection set-up)
+                    barrier()
+                    t0g = time.perf_counter()
+                    got = mdist.gather_results(local, n_total, force=True)
+                    barrier()
+                    ms.append((time.perf_counter() - t0g) * 1e3)
+                gathered.update(got)
+                state["gather_ms"] = ms
+            else:
+                gathered.update({k: np.asarray(v) for k, v in local.items()})
 
     def barrier():
         if use_dist:
@@ -352,15 +410,49 @@ def main():
     dt_local = dt
     mc_total, res = state["mc"], state["res"]
     gather_last()
-    # The dominant kernel by itself, for the roofline objects: with several streams an analysis' HIP events bracket the other
-    # streams' kernels too, so a few analyses are run ALONE on one stream behind the timed region and their event times taken
-    # (that is also what the committed rocprofv3 passes characterise: tools/profile_r03.sh runs --streams 1 --inflight 1).
+    # The dominant kernel by itself, for the roofline objects.  One stream (the default): an analysis' HIP events bracket its own
+    # tick kernels only, the per-analysis event times ARE the kernel's.  Several streams (--streams 2): the events bracket the other
+    # streams' kernels too, so a few analyses are run ALONE behind the timed region (that is also what the committed rocprofv3
+    # passes characterise: tools/profile.sh runs --streams 1 --inflight 1).
     solo_ms = []
     if not dry and len(plans) > 1:
         for i in range(8):
             plan.reseed(seed + i, first); plan.launch(); plan.fetch(want_arrays=False)
             if i >= 2:
                 solo_ms.append(plan.last_ms)
+    # A SERIES of data sets (gui/calc.py:271-330; mcsas_amd.run_series(overlap=True)): two plans on streams of their own, two result
+    # slots each, launch order A0 B0 A1 B1 — an analysis' scan-bound first ticks run beside another's producer-bound last ones.
+    series = None
+    if not dry and len(plans) == 1 and world == 1 and args.config == 2 and not args.no_series:
+        series = series_two_streams(engine, torch, setup, q, I, sigma, st, first, seed + 100)
+    # Strong scaling of config 2 beside the weak headline: its 50 repetitions IN ALL, sharded over the ranks (6-7 chains per GPU)
+    strong = None
+    if not dry and world > 1 and args.config == 2 and args.scaling == "weak":
+        f2, r2 = mdist.shard_reps(wl["reps_total"], world, rank)
+        st2 = engine.Settings(n_contrib=ncontrib, n_reps=r2, max_iter=mc_steps, conv_crit=0.0, max_retries=0, seed=20250101,
+                              rep_offset=f2, device=dev_index, waves_per_chain=args.waves, exec_mode=args.mode)
+        pl2 = engine.Plan(setup, q, I, sigma, st2)
+        nl = max(4, lps)
+        for i in range(3):
+            pl2.reseed(5000 + i, f2); pl2.launch(); pl2.fetch(want_arrays=False)
+        barrier()
+        t0s = time.perf_counter()
+        steps2 = 0
+        for i in range(nl):
+            pl2.reseed(5100 + i, f2); pl2.launch(slot=i & 1)
+            if i >= 1:
+                pl2.fetch(want_arrays=False, slot=(i - 1) & 1); steps2 += pl2.total_steps
+        pl2.fetch(want_arrays=False, slot=(nl - 1) & 1); steps2 += pl2.total_steps
+        barrier()
+        dts = time.perf_counter() - t0s
+        tt = torch.tensor([dts, float(steps2)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tmx = tt.clone(); tdist.all_reduce(tmx, op=tdist.ReduceOp.MAX)
+        tsm = tt.clone(); tdist.all_reduce(tsm, op=tdist.ReduceOp.SUM)
+        strong = {"value": float(tsm[1]) / float(tmx[0]), "unit": "MC steps/s", "scaling": "strong", "reps_total": wl["reps_total"],
+                  "reps_this_rank": r2, "launches": nl, "timed_region_s": float(tmx[0]), "window": pl2.info["window"],
+                  "note": "config 2's 50 repetitions in all, sharded over the ranks: 6-7 chains per GPU, where an analysis is bound "
+                          "by the per-tick latency of the pipeline (3.1 ms for 7 chains against 3.4 for 50 on one GPU), not by throughput"}
+        pl2.close()
     ranks_seen = 1
     if use_dist:
         dev = "cuda" if backend == "nccl" and not dry else "cpu"
@@ -375,10 +467,8 @@ def main():
         if args.dump:
             np.savez(args.dump, **gathered)
         lm = np.array(launch_ms) if launch_ms else np.zeros(1)
-        # device time of one analysis: its HIP-event time on its stream — or, with several streams whose kernels share the chip
-        # (an analysis' events then bracket the other analyses' kernels too), this rank's timed region / its analyses
         overlapped = len(plans) > 1
-        launch_eff_s = (dt_local / max(len(launch_ms), 1)) if overlapped else float(lm.mean()) * 1e-3
+        launch_eff_s = dt_local / max(len(launch_ms), 1)                               # this rank's timed region / its analyses
         launch_s = float(np.mean(solo_ms)) * 1e-3 if solo_ms else float(lm.mean()) * 1e-3     # one analysis alone on the chip
         steps_per_launch = mc_total / max(len(launch_ms), 1)
         nq = len(q)
@@ -390,69 +480,272 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "dry-run" if dry else ("synthetic" if args.config != 5 else "testdata/sasfit_kho-1-10-1000.dat (reference data file)"),
-            "config": {"workload": "%s, %d reps on this rank (%d in all), %d MC steps per chain per launch, convergenceCriterion=0"
-                                   % (wl["name"], reps, n_total, mc_steps),
-                       "baseline_config": args.config, "reps_total": n_total, "launches_per_step": lps,
+            "config": {"workload": "%s, %d reps on this rank (%d in all), %d MC steps per chain per launch, convergenceCriterion=0, "
+                                   "%s" % (wl["name"], reps, n_total, mc_steps,
+                                           "one analysis on the chip at a time" if not overlapped else "%d analyses side by side" % len(plans)),
+                       "baseline_config": args.config, "reps_total": n_total, "reps_per_gpu": reps, "launches_per_step": lps,
                        "ranks_seen": ranks_seen, "streams": len(plans), "result_slots": nslots, **info},
             "timed_region_s": dt,
             "launch_ms": {"n": int(len(lm)), "min": float(lm.min()), "median": float(np.median(lm)), "max": float(lm.max()),
                           "mean": float(lm.mean()),
                           "note": "HIP events around each analysis on its stream" + ("; %d streams share the chip, so an analysis' events "
-                                  "span the other streams' kernels as well: effective_ms is the timed region / analyses" % len(plans) if overlapped else "")},
+                                  "span the other streams' kernels as well: effective_ms is the timed region / analyses" % len(plans) if overlapped else
+                                  " (one stream: the analysis' own tick kernels)")},
             "launch_ms_effective": launch_eff_s * 1e3,
             "launch_ms_solo": {"n": len(solo_ms), "mean": float(np.mean(solo_ms)), "min": float(np.min(solo_ms)), "max": float(np.max(solo_ms)),
-                               "note": "analyses run alone on one stream behind the timed region: the kernel time the roofline objects use"} if solo_ms else None,
+                               "note": "analyses run alone on one stream behind the timed region: the kernel time the roofline objects use"} if solo_ms else
+                              {"n": int(len(lm)), "mean": float(lm.mean()), "min": float(lm.min()), "max": float(lm.max()),
+                               "note": "= launch_ms: one stream, an analysis' events bracket its own kernels only"},
         }
+        if state["gather_ms"]:
+            gm = state["gather_ms"]
+            out["gather_ms"] = {"first": gm[0], "steady": float(np.min(gm[1:])) if len(gm) > 1 else None, "backend": backend, "ranks": world,
+                                "bytes_per_rank": int(8 * reps * (ncontrib * setup.n_active + len(q) + 3)),
+                                "note": "one packed all-gather of the last analysis' per-repetition results (mcsas_amd/dist.py), outside the timed "
+                                        "region: nothing in an analysis needs another rank"}
+        if series:
+            out["series_two_streams"] = series
+        if strong:
+            out["strong_scaling"] = strong
         if not dry:
             out["final_chisq_median"] = float(np.median(res.chisq))
+            out["chisq_of_truth"] = wl["chisq_of_truth"]
             # SURVEY 8d streaming model: 40*Q bytes per MC step against the HBM peak.  Chain state (q, I, sigma, ft)
             # actually stays on chip, so this is an algorithmic figure; `traffic` is what the memory-side
             # counters saw for the same command in the committed profile named in `traffic_source`.
             traffic, source = None, None
-            tj = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-            pm = json.load(open(tj)).get(str(args.config)) if os.path.exists(tj) else None
+            tj, pmt = latest_profile("pmc_traffic.json")
+            pm = pmt.get(str(args.config))
             if pm and info["exec_mode"] == "pipeline" and reps == wl["reps_gpu"]:
                 traffic = (pm["fetch_bytes_per_mc_step"] + pm["write_bytes_per_mc_step"]) * steps_per_launch / launch_s / 1e9
-                source = "from_profile: %s (commit %s)" % (os.path.relpath(tj, ROOT), pm.get("commit", "?"))
+                source = "from_profile: %s (commit %s)" % (tj, pm.get("commit", "?"))
             algorithmic = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                            "note": "40*Q B per MC step (SURVEY 8d streaming model, no on-chip reuse credit) x MC steps per launch / mean "
                                    "HIP-event time of a launch; q, I, sigma and ft stay on chip, so this is not memory traffic"}
-            ij = os.path.join(ROOT, "profiles", "r03_valu_per_step.json")
-            pv = json.load(open(ij)).get(str(args.config)) if os.path.exists(ij) else None
+            ij, pvt = latest_profile("valu_per_step.json")
+            pv = pvt.get(str(args.config))
             if pv and info["exec_mode"] == "pipeline":
                 rate = pv["valu_wave_instr_per_mc_step"] * steps_per_launch / launch_s
                 out["roofline_valu"] = {"bound": "valu", "achieved": rate / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9,
                                         "unit": "G wave-instr/s", "frac": rate / FP64_VECTOR_PEAK_INSTR,
                                         "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
-                                        "source": "from_profile: profiles/r03_valu_per_step.json (SQ_INSTS_VALU pass, commit %s)" % pv.get("commit", "?"),
+                                        "source": "from_profile: %s (SQ_INSTS_VALU pass, commit %s)" % (ij, pv.get("commit", "?")),
                                         "note": "fp64 vector issue: 1024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz; achieved = "
                                                 "SQ_INSTS_VALU per MC step (committed counter pass) x MC steps per launch / mean HIP-event time of a launch"}
             out["roofline"] = dict(algorithmic, traffic=traffic, traffic_unit="GB/s", traffic_source=source)
         # outside the timed region: the same repetitions run the way McSAS.analyse runs them — convergenceCriterion 1 (BASELINE),
-        # maxIterations 1e5, one attempt — -> final chi² and how many got there.  (With 1 % noise on the synthetic curve 400
-        # spheres plateau near chi² 1.15: the criterion is out of reach on THIS data set and every chain runs its full budget;
-        # the reference's own published workload, where criterion 1 is reached, is the `quickstart` entry.)
-        if not dry and not args.no_convergence_run and args.config == 2:
-            stc = engine.Settings(n_contrib=ncontrib, n_reps=reps, max_iter=100000, conv_crit=1.0, max_retries=0,
-                                  seed=20250101, rep_offset=first, device=dev_index, exec_mode=args.mode)
-            t0 = time.perf_counter()
-            conv = engine.analyse(setup, q, I, sigma, stc)
-            wall = time.perf_counter() - t0
-            out["convergence_run"] = {"criterion": 1.0, "max_iterations": 100000, "wall_s": wall,
-                                      "converged": int(conv.converged.sum()), "reps": reps,
-                                      "chisq_min": float(conv.chisq.min()), "chisq_median": float(np.median(conv.chisq)),
-                                      "chisq_max": float(conv.chisq.max()), "steps_mean": float(conv.num_iter.mean()),
-                                      "mc_steps_per_s_incl_setup": float(conv.num_iter.sum()) / wall}
+        # maxIterations 1e5, one attempt — -> final chi² and how many got there, to be read against chisq_of_truth.
+        if not dry and not args.no_convergence_run:
+            out["convergence_run"] = convergence_run(engine, setup, q, I, sigma, ncontrib, reps, first, dev_index, wl["chisq_of_truth"], args.mode)
         if not dry and not args.no_convergence_run and world == 1 and args.config == 2:
+            out["calc_breakdown"] = calc_breakdown(wl, dev_index)
             out["quickstart"] = quickstart(dev_index)
         if not dry and not args.no_configs and world == 1 and args.config == 2:
             out["configs"] = other_configs(dev_index)
+        if not dry and not args.no_many_chains and not args.no_configs and world == 1 and args.config == 2:
+            out["many_chains"] = many_chains(wl, dev_index)
         if not dry and not args.no_cpu_baseline and world == 1 and args.config == 2:   # the CPU baseline is timed at N = 1 only
             lo, hi = np.pi / q.max(), np.pi / q.min()
             out["cpu_baseline"] = cpu_baseline(q, I, sigma, lo, hi)
         print(json.dumps(out))
     if use_dist:
         tdist.destroy_process_group()
+
+
+def latest_profile(suffix):
+    """(relative path, parsed JSON) of the newest committed profiles/rNN_<suffix>, ({} when there is none)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    if not c:
+        return None, {}
+    return os.path.relpath(c[-1], ROOT), json.load(open(c[-1]))
+
+
+def convergence_run(engine, setup, q, I, sigma, ncontrib, reps, first, dev_index, chisq_of_truth, mode=0, max_iter=100000):
+    """The workload's repetitions the way McSAS.analyse runs them (mcsas.py:191-285): criterion 1 (BASELINE / SURVEY 8d), maxIterations
+    1e5, one attempt per repetition.  Second leg when criterion 1 is below what the data allow (it asks for a chi² under the ground
+    truth's own): the same at 1.15 x chisq_of_truth, i.e. the criterion a user of the reference would set for this curve."""
+    def run(crit):
+        stc = engine.Settings(n_contrib=ncontrib, n_reps=reps, max_iter=max_iter, conv_crit=crit, max_retries=0,
+                              seed=20250101, rep_offset=first, device=dev_index, exec_mode=mode)
+        t0 = time.perf_counter()
+        conv = engine.analyse(setup, q, I, sigma, stc)
+        wall = time.perf_counter() - t0
+        return {"criterion": crit, "max_iterations": max_iter, "wall_s": wall, "converged": int(conv.converged.sum()), "reps": reps,
+                "chisq_min": float(conv.chisq.min()), "chisq_median": float(np.median(conv.chisq)), "chisq_max": float(conv.chisq.max()),
+                "steps_mean": float(conv.num_iter.mean()), "mc_steps_per_s_incl_setup": float(conv.num_iter.sum()) / wall}
+    out = run(1.0)
+    out["chisq_of_truth"] = chisq_of_truth
+    if chisq_of_truth is not None and out["converged"] < reps:
+        out["at_reachable_criterion"] = run(round(1.15 * chisq_of_truth, 3))
+    return out
+
+
+def series_two_streams(engine, torch, setup, q, I, sigma, st, first, seed, seconds=1.0):
+    """Whole-job rate of back-to-back analyses with TWO plans on streams of their own, two result slots each."""
+    pls = [engine.Plan(setup, q, I, sigma, st) for _ in range(2)]
+    sts = [torch.cuda.Stream() for _ in pls]
+    lanes2 = [(k, sl) for sl in range(2) for k in range(2)]
+    pend, steps, n = [], 0, 0
+
+    def retire():
+        k, sl = pend.pop(0)
+        pls[k].fetch(slot=sl)
+        return pls[k].total_steps
+
+    for i in range(8):                                        # warm-up: every slot twice
+        k, sl = lanes2[i % 4]
+        while (k, sl) in pend:
+            retire()
+        pls[k].reseed(seed + i, first); pls[k].launch(stream=sts[k].cuda_stream, slot=sl); pend.append((k, sl))
+    while pend:
+        retire()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while True:
+        k, sl = lanes2[n % 4]
+        while (k, sl) in pend or len(pend) >= 4:
+            steps += retire()
+        pls[k].reseed(seed + 50 + n, first); pls[k].launch(stream=sts[k].cuda_stream, slot=sl); pend.append((k, sl)); n += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    while pend:
+        steps += retire()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for pl in pls:
+        pl.close()
+    return {"value": steps / dt, "unit": "MC steps/s", "streams": 2, "result_slots": 2, "analyses": n, "timed_region_s": dt,
+            "ms_per_analysis_effective": dt / n * 1e3,
+            "note": "throughput of a series of data sets (mcsas_amd.run_series(overlap=True)): two analyses share the chip; not the "
+                    "latency of one analysis"}
+
+
+def calc_breakdown(wl, dev_index, trials=5):
+    """McSAS.calc() of config 2 through the front end (mcsas_amd.McSAS), split into its two halves: analyse() (mcsas.py:191-285) and
+    histogram() (:445-615) with one 50-bin volume-weighted log histogram — fixed budget of 20 000 steps, showIncomplete."""
+    import mcsas_amd
+    q = wl["q"]
+    ta, th = [], []
+    for t in range(trials):
+        m = mcsas_amd.Sphere(); m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
+        lo, hi = m.radius.activeRange()
+        m.radius.histograms().append(mcsas_amd.Histogram(m.radius, lo, hi, binCount=50, xscale='log', yweight='vol'))
+        algo = mcsas_amd.McSAS(seed=900 + t, device=dev_index)
+        algo.numContribs.setValue(wl["n"]); algo.numReps.setValue(wl["reps_gpu"]); algo.maxIterations.setValue(20000)
+        algo.convergenceCriterion.setValue(0.0); algo.showIncomplete.setValue(True)
+        algo.maxRetries = mcsas_amd.mcsas._Setting("maxRetries", 0)          # one attempt: the fixed budget of the timed workload
+        algo.model = m
+        algo.data = mcsas_amd.SASData(q, wl["I"], wl["sigma"])
+        algo.result = []; algo.stop = False
+        logging_off = __import__("logging"); logging_off.disable(logging_off.WARNING)
+        t0 = time.perf_counter(); algo.analyse(); t1 = time.perf_counter(); algo.histogram(); t2 = time.perf_counter()
+        logging_off.disable(logging_off.NOTSET)
+        ta.append((t1 - t0) * 1e3); th.append((t2 - t1) * 1e3)
+    ta, th = np.array(ta[1:]), np.array(th[1:])
+    return {"analyse_ms": float(np.median(ta)), "histogram_ms": float(np.median(th)), "calc_ms": float(np.median(ta + th)),
+            "histogram_over_analyse": float(np.median(th) / np.median(ta)),
+            "workload": "config 2 through mcsas_amd.McSAS: 50 reps x 400 contribs x 20000 steps, one 50-bin log histogram (vol); wall times"}
+
+
+class ClockSampler(object):
+    """sclk / socket power of the GPU while a region runs, read from sysfs (hwmon freq1_input / power1_average|power1_input of the
+    device's card) every 50 ms on a thread: backs the statement that the wave-per-chain rate follows the chip's power state."""
+
+    def __init__(self, dev_index):
+        import glob
+        self.freq, self.power = None, None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
+        if cards:
+            c = cards[min(dev_index if dev_index >= 0 else 0, len(cards) - 1)]
+            self.freq = os.path.join(c, "freq1_input")
+            for name in ("power1_average", "power1_input"):
+                if os.path.exists(os.path.join(c, name)):
+                    self.power = os.path.join(c, name)
+                    break
+        self.samples, self._stop, self._th = [], False, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            return float(open(path).read().split()[0])
+        except Exception:
+            return None
+
+    def _loop(self):
+        while not self._stop:
+            f = self._read(self.freq) if self.freq else None
+            p = self._read(self.power) if self.power else None
+            self.samples.append((time.perf_counter(), f, p))
+            time.sleep(0.05)
+
+    def __enter__(self):
+        import threading
+        if self.freq:
+            self._th = threading.Thread(target=self._loop, daemon=True); self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th:
+            self._th.join()
+
+    def summary(self):
+        f = np.array([s[1] for s in self.samples if s[1] is not None]) / 1e6          # Hz -> MHz
+        p = np.array([s[2] for s in self.samples if s[2] is not None]) / 1e6          # uW -> W
+        if not len(f):
+            return {"available": False, "note": "no hwmon freq1_input for the card: clocks not sampled"}
+        out = {"available": True, "samples": int(len(f)), "sclk_mhz": {"min": float(f.min()), "median": float(np.median(f)), "max": float(f.max())},
+               "source": self.freq}
+        if len(p):
+            out["power_w"] = {"min": float(p.min()), "median": float(np.median(p)), "max": float(p.max())}
+        return out
+
+
+def many_chains(wl, dev_index, reps=8192, mc_steps=2000, seconds=1.5):
+    """The kernel north_star describes literally — one wavefront per chain, thousands of chains: Sphere 512 q x 400 contributions,
+    8192 repetitions, MCSAS_EXEC_WAVE, back-to-back launches of 2000 steps per chain sustained over >= `seconds`, clocks and power
+    sampled beside it."""
+    import torch
+    from mcsas_amd import engine
+    setup = wl["model"].setup()
+    st = engine.Settings(n_contrib=wl["n"], n_reps=reps, max_iter=mc_steps, conv_crit=0.0, max_retries=0, seed=20250101,
+                         device=dev_index, exec_mode=engine.EXEC_WAVE)
+    plan = engine.Plan(setup, wl["q"], wl["I"], wl["sigma"], st)
+    for i in range(2):
+        plan.reseed(40 + i, 0); plan.launch(); plan.fetch(want_arrays=False)
+    torch.cuda.synchronize()
+    ms, steps, n = [], 0, 0
+    with ClockSampler(dev_index) as cs:
+        t0 = time.perf_counter()
+        while True:
+            plan.reseed(50 + n, 0); plan.launch(); plan.fetch(want_arrays=False)
+            ms.append(plan.last_ms); steps += plan.total_steps; n += 1
+            if time.perf_counter() - t0 >= seconds:
+                break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    info = plan.info
+    plan.close()
+    engine.release_cached_memory()
+    rate = steps / dt
+    e = {"workload": "Sphere 512 q x 400 contribs, %d reps, one wavefront per chain, %d MC steps per chain per launch" % (reps, mc_steps),
+         "value": rate, "unit": "MC steps/s", "timed_region_s": dt, "launches": n, "exec_mode": info["exec_mode"],
+         "waves_per_chain": info["waves_per_chain"], "q_per_lane": info["q_per_lane"],
+         "launch_ms": {"min": float(np.min(ms)), "median": float(np.median(ms)), "max": float(np.max(ms))},
+         "rate_of_fastest_launch": reps * mc_steps / (float(np.min(ms)) * 1e-3), "rate_of_slowest_launch": reps * mc_steps / (float(np.max(ms)) * 1e-3),
+         "clocks": cs.summary(),
+         "roofline": {"bound": "hbm", "achieved": 40 * len(wl["q"]) * rate / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                      "frac": 40 * len(wl["q"]) * rate / HBM_PEAK}}
+    ij, pvt = latest_profile("valu_per_step.json")
+    pv = pvt.get("wave8192")
+    if pv:
+        r = pv["valu_wave_instr_per_mc_step"] * rate
+        e["roofline_valu"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
+                              "frac": r / FP64_VECTOR_PEAK_INSTR, "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
+                              "source": "from_profile: %s (commit %s)" % (ij, pv.get("commit", "?"))}
+    return e
 
 
 def other_configs(dev_index, seconds=1.0):
@@ -464,12 +757,10 @@ def other_configs(dev_index, seconds=1.0):
     import torch
     from mcsas_amd import engine
     out = {}
-    ij = os.path.join(ROOT, "profiles", "r03_valu_per_step.json")
-    prof = json.load(open(ij)) if os.path.exists(ij) else {}
-    tj = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-    traf = json.load(open(tj)) if os.path.exists(tj) else {}
+    ij, prof = latest_profile("valu_per_step.json")
+    tj, traf = latest_profile("pmc_traffic.json")
     for cfg, budget in ((3, 10000), (4, 5000), (5, 5000)):
-        wl = workload(cfg)
+        wl = workload(cfg, dev_index)
         setup = wl["model"].setup()
         st0 = engine.Settings(n_contrib=wl["n"], n_reps=wl["reps_gpu"], max_iter=0, conv_crit=0.0, max_retries=0,
                               seed=20250101, device=dev_index)
@@ -538,7 +829,11 @@ def other_configs(dev_index, seconds=1.0):
                             "launch_ms": {"min": float(np.min(ms)), "median": float(np.median(ms)), "max": float(np.max(ms))},
                             "init_ms": init, "value_excl_init": steps / max(dev_s - n * init * 1e-3, 1e-9)},
              "exec_mode": info["exec_mode"], "window": info["window"], "final_chisq_median": float(np.median(res.chisq)),
+             "chisq_of_truth": wl["chisq_of_truth"],
              "ff_points_per_s": rate * pts, "ff_points_per_mc_step": pts}
+        # the same repetitions run to BASELINE's criterion (1, maxIterations 1e5, one attempt): final chi² and how many got there
+        e["convergence_run"] = convergence_run(engine, setup, wl["q"], wl["I"], wl["sigma"], wl["n"], wl["reps_gpu"], 0, dev_index,
+                                               wl["chisq_of_truth"])
         # (roofline objects: the kernels of one analysis by themselves, like the main workload's)
         alg = {"bound": "hbm", "achieved": 40 * nq * rate_one / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": 40 * nq * rate_one / HBM_PEAK}
         pv = prof.get(str(cfg))
@@ -549,7 +844,7 @@ def other_configs(dev_index, seconds=1.0):
             r = pv["valu_wave_instr_per_mc_step"] * rate_one
             e["roofline_valu"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
                                   "frac": r / FP64_VECTOR_PEAK_INSTR, "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
-                                  "source": "from_profile: profiles/r03_valu_per_step.json / r03_pmc_traffic.json (commit %s)" % pv.get("commit", "?")}
+                                  "source": "from_profile: %s / %s (commit %s)" % (ij, tj, pv.get("commit", "?"))}
         out[str(cfg)] = e
     return out
 

@@ -193,7 +193,38 @@ static Plugin *plugin_of(int model_id) {
 }
 
 // one translation unit: the kernel headers, the plug-in's Contrib, the plug-in text; `exprs` = the kernels to instantiate
-static int plugin_compile_program(const std::string &source, const std::vector<std::string> &exprs, Plugin::Program *out) {
+// value of the LAST `#define KEY value` line of the text (whitespace after '#' and around the name, parentheses around the
+// value allowed), `dflt` when there is none.  What this returns is checked against the preprocessor (see mcsas_hip_plugin_compile).
+static long plugin_scan_define(const std::string &src, const char *key, long dflt) {
+    long val = dflt;
+    const size_t klen = strlen(key);
+    size_t pos = 0;
+    while (pos < src.size()) {
+        size_t eol = src.find('\n', pos);
+        if (eol == std::string::npos) eol = src.size();
+        size_t i = pos;
+        auto skip_ws = [&]() { while (i < eol && (src[i] == ' ' || src[i] == '\t')) ++i; };
+        skip_ws();
+        if (i < eol && src[i] == '#') {
+            ++i; skip_ws();
+            if (src.compare(i, 6, "define") == 0) {
+                i += 6;
+                const size_t before = i;
+                skip_ws();
+                if (i > before && src.compare(i, klen, key) == 0 && (i + klen >= eol || src[i + klen] == ' ' || src[i + klen] == '\t')) {
+                    i += klen; skip_ws();
+                    while (i < eol && src[i] == '(') { ++i; skip_ws(); }
+                    val = i < eol ? strtol(src.c_str() + i, nullptr, 0) : 1;     // `#define KEY` alone: defined, i.e. 1 where it is used as a flag
+                }
+            }
+        }
+        pos = eol + 1;
+    }
+    return val;
+}
+
+static int plugin_compile_program(const Plugin &pg, const std::vector<std::string> &exprs, Plugin::Program *out) {
+    const std::string &source = pg.source;
     // hiprtc has the fixed-width integer types in a namespace of its own
     std::string tu =
         "typedef signed char int8_t; typedef unsigned char uint8_t; typedef short int16_t; typedef unsigned short uint16_t;\n"
@@ -207,7 +238,10 @@ static int plugin_compile_program(const std::string &source, const std::vector<s
     if (r != HIPRTC_SUCCESS) return fail(MCSAS_EHIP, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     for (const std::string &e : exprs) hiprtcAddNameExpression(prog, e.c_str());
     // the flags of the Makefile: one contribution row must come out the same from every call site (-ffp-contract=off)
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value"};
+    char host_rc[48], host_cs[48];
+    snprintf(host_rc, sizeof host_rc, "-DMCSAS_HOST_ROW_CLASS=%d", pg.row_class);
+    snprintf(host_cs, sizeof host_cs, "-DMCSAS_HOST_CAN_SMEAR=%d", pg.can_smear ? 1 : 0);
+    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", host_rc, host_cs};
     r = hiprtcCompileProgram(prog, (int)(sizeof opts / sizeof opts[0]), opts);
     size_t ls = 0;
     g_plugin_log.clear();
@@ -240,7 +274,7 @@ static int plugin_function(int model_id, const std::string &key, const std::vect
     auto it = pg->programs.find(key);
     if (it == pg->programs.end()) {
         Plugin::Program prg;
-        int rc = plugin_compile_program(pg->source, exprs, &prg);
+        int rc = plugin_compile_program(*pg, exprs, &prg);
         if (rc) return rc;
         it = pg->programs.emplace(key, std::move(prg)).first;
     }
@@ -308,18 +342,17 @@ extern "C" int mcsas_hip_plugin_compile(const char *source, int32_t *model_id) {
     // the small kernels are compiled here, so that a plug-in that does not compile is refused before anything uses it
     auto pg = std::make_unique<Plugin>();
     pg->source = source;
-    {   // the row class the text declares (the kernels see the macro; the host needs the number for the pipeline's geometry)
-        const char *key = "MCSAS_PLUGIN_ROW_CLASS";
-        size_t at = pg->source.find(std::string("#define ") + key);
-        if (at != std::string::npos) pg->row_class = atoi(pg->source.c_str() + at + 8 + strlen(key));
-        if (pg->row_class < 0 || pg->row_class > 1) return fail(MCSAS_EINVAL, "MCSAS_PLUGIN_ROW_CLASS %d (0 or 1)", pg->row_class);
-        const char *key2 = "MCSAS_PLUGIN_CAN_SMEAR";
-        at = pg->source.find(std::string("#define ") + key2);
-        if (at != std::string::npos) pg->can_smear = atoi(pg->source.c_str() + at + 8 + strlen(key2)) != 0;
-    }
+    // The row class and the canSmear flag the text declares: the host needs the numbers for the pipeline's geometry and for the
+    // smearing tables, the kernels see the macros.  The host's reading of the text (a line-wise scan for `# define KEY value`)
+    // is passed to EVERY compilation of this plug-in as -DMCSAS_HOST_ROW_CLASS / -DMCSAS_HOST_CAN_SMEAR and plugin_model.h
+    // static_asserts that the preprocessor's values are the same: a text the scan misreads (a define inside a comment or an
+    // `#if 0`, an expression for a value) does not compile and is refused here instead of running with two different answers.
+    pg->row_class = (int)plugin_scan_define(pg->source, "MCSAS_PLUGIN_ROW_CLASS", 0);
+    pg->can_smear = plugin_scan_define(pg->source, "MCSAS_PLUGIN_CAN_SMEAR", 0) != 0;
+    if (pg->row_class < 0 || pg->row_class > 1) return fail(MCSAS_EINVAL, "MCSAS_PLUGIN_ROW_CLASS %d (0 or 1)", pg->row_class);
     Plugin::Program prg;
     const std::vector<std::string> exprs(PLUGIN_SMALL_EXPRS, PLUGIN_SMALL_EXPRS + 3);
-    int rc = plugin_compile_program(pg->source, exprs, &prg);
+    int rc = plugin_compile_program(*pg, exprs, &prg);
     if (rc) return rc;
     pg->programs.emplace("small", std::move(prg));
     std::lock_guard<std::mutex> lk(g_plugins_mu);

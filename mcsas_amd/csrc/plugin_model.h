@@ -28,6 +28,17 @@
 #define MCSAS_PLUGIN_CAN_SMEAR 0
 #endif
 
+// The library's host side read the two values off the text by itself (mcsas_hip_plugin_compile) and hands its reading in: the
+// geometry the host picks and the kernel instantiated here must agree on them, so a text the host misreads is refused.
+#ifdef MCSAS_HOST_ROW_CLASS
+static_assert((MCSAS_PLUGIN_ROW_CLASS) == MCSAS_HOST_ROW_CLASS,
+              "MCSAS_PLUGIN_ROW_CLASS: write it as a plain `#define MCSAS_PLUGIN_ROW_CLASS 0|1` line (the library's host side read another value off the text)");
+#endif
+#ifdef MCSAS_HOST_CAN_SMEAR
+static_assert(((MCSAS_PLUGIN_CAN_SMEAR) != 0) == (MCSAS_HOST_CAN_SMEAR != 0),
+              "MCSAS_PLUGIN_CAN_SMEAR: write it as a plain `#define MCSAS_PLUGIN_CAN_SMEAR 0|1` line (the library's host side read another value off the text)");
+#endif
+
 __device__ double mcsas_plugin_formfactor(double q, const double *p);
 __device__ double mcsas_plugin_volume(const double *p);
 __device__ double mcsas_plugin_absvolume(const double *p);

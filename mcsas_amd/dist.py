@@ -30,13 +30,14 @@ def _gather_var(t, counts, dist, device):
     return torch.cat([o[:c] for o, c in zip(out, counts)], dim=0)
 
 
-def gather_results(local: dict, n_reps: int, device=None):
+def gather_results(local: dict, n_reps: int, device=None, force=False):
     """`local`: per-rank arrays with the REP AXIS FIRST (e.g. contribs as (R_local, N, P)).
     Returns the same keys with all reps, in rep order, on every rank.  One fused all-gather:
-    everything is packed into a single (R_local, width) float64 buffer."""
+    everything is packed into a single (R_local, width) float64 buffer.  `force`: go through the
+    collective also at world size 1 (a one-GPU box exercising the RCCL path)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return {k: np.asarray(v) for k, v in local.items()}
     ws, rank = dist.get_world_size(), dist.get_rank()
     counts = [shard_reps(n_reps, ws, r)[1] for r in range(ws)]

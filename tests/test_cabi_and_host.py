@@ -214,6 +214,17 @@ def test_model_plugins_compile_without_a_gpu_and_report_compiler_errors():
     with pytest.raises(engine.PluginCompileError) as e:
         engine.compile_plugin(PLUGIN_SOURCES["gausschain"].replace("p[3] * (p[0] * p[0])", "p[3] * rg_squared"))
     assert "rg_squared" in e.value.log and "plugin:" in e.value.log          # (line numbers refer to the plug-in text)
+    # the row class / canSmear flag: any spelling the preprocessor accepts on a `#define` line is read the same way by the host,
+    # and a text where host and preprocessor would disagree (the define sits in a dead `#if 0` block) is refused
+    base = PLUGIN_SOURCES["gausschain"]
+    for spelled in ("#define MCSAS_PLUGIN_ROW_CLASS (1)\n", "#  define\tMCSAS_PLUGIN_ROW_CLASS\t1\n", "  # define MCSAS_PLUGIN_ROW_CLASS 0x1\n",
+                    "// #define MCSAS_PLUGIN_ROW_CLASS 1 (comment: not a define)\n#define MCSAS_PLUGIN_CAN_SMEAR 1\n"):
+        assert engine.compile_plugin(spelled + base) >= engine.MODEL_PLUGIN0
+    for dead in ("#if 0\n#define MCSAS_PLUGIN_ROW_CLASS 1\n#endif\n", "/*\n#define MCSAS_PLUGIN_CAN_SMEAR 1\n*/\n",
+                 "#define MCSAS_PLUGIN_ROW_CLASS 1\n#undef MCSAS_PLUGIN_ROW_CLASS\n#define MCSAS_PLUGIN_ROW_CLASS (2 - 2)\n"):
+        with pytest.raises(engine.PluginCompileError) as e:
+            engine.compile_plugin(dead + base)
+        assert "host side read another value" in e.value.log
     # host mirror: a model class of the user's own with a `hipSource` attribute flattens like a built-in one
     m, _ = make_models("gausschain")
     s0 = m.setup()

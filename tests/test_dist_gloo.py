@@ -90,6 +90,29 @@ def test_bench_multi_rank_path_equals_single_rank(tmp_path, extra):
         np.testing.assert_array_equal(a1[k], a2[k])
 
 
+def test_bench_forced_collective_at_world_size_one(tmp_path):
+    """MCSAS_BENCH_FORCE_DIST=1: one rank, but through the process group, the packed all-gather (timed: gather_ms) and the
+    all-reduce of the timings — the switch the GPU suite uses to run the RCCL path on a one-GPU box."""
+    one, a1 = _run_bench(tmp_path, 1, ["--scaling", "strong"], "plain")
+    os.environ["MCSAS_BENCH_FORCE_DIST"] = "1"
+    try:
+        forced, a2 = _run_bench(tmp_path, 1, ["--scaling", "strong"], "forced")
+    finally:
+        del os.environ["MCSAS_BENCH_FORCE_DIST"]
+    assert "gather_ms" not in one and forced["gather_ms"]["ranks"] == 1 and forced["gather_ms"]["backend"] == "gloo"
+    assert forced["config"]["ranks_seen"] == 1 and forced["n_gpus"] == 1
+    for k in ("contribs", "fit", "chisq", "scaling", "background"):
+        np.testing.assert_array_equal(a1[k], a2[k])
+
+
+def test_bench_default_scaling_follows_the_config(tmp_path):
+    """Config 2 is named per GPU (50 repetitions on 1 MI355X): weak by default; configs 3-5 are named as totals over 8 GPUs: strong."""
+    two, _ = _run_bench(tmp_path, 2, [], "c2")
+    assert two["scaling"] == "weak" and two["config"]["reps_total"] == 100 and two["config"]["reps_per_gpu"] == 50
+    five, _ = _run_bench(tmp_path, 2, ["--config", "5"], "c5")
+    assert five["scaling"] == "strong" and five["config"]["reps_total"] == 100 and five["config"]["reps_per_gpu"] == 50
+
+
 def test_bench_refuses_a_world_size_it_was_not_asked_for(tmp_path):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -89,7 +89,31 @@ TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q5
         "g9_cyl_q512.npz", "g9_ellcs_q1024.npz", "g9_kho_q64.npz", "g9_kho_q512.npz",
         # round 3: config 2's shape (512 q x 400) over long budgets — 25 000 fixed steps (62 sweeps over the contributions) and a
         # chain that the reference ends by convergence (criterion 2, 5509 steps)
-        "g14_sphere_q512_long.npz", "g14_sphere_q512_converge.npz"]
+        "g14_sphere_q512_long.npz", "g14_sphere_q512_converge.npz",
+        # round 4: chains the reference ENDS BY CONVERGENCE (criterion 1) for models with an orientation integral (cylinders 6228
+        # steps, core-shell ellipsoids 1887 steps; 100 q x 200 contributions) and with positiveBackground (sphere, criterion 2, 5768 steps)
+        "g17_cyl_q100_converge.npz", "g17_ellcs_q100_converge.npz", "g17_sphere_q100_posbg_converge.npz"]
+
+
+def test_g17_positive_background_chain_that_only_minpack_follows():
+    """A positiveBackground chain run to criterion 1 on data whose background is ~0 (g17_..._posbg_minpack, oracle/make_golden.py
+    gen_converging_trajectories): the fit sits next to the |b| kink and the reference's MINPACK stops up to 1e-6 above the minimum,
+    which decides a late step.  The call-for-call leastsq restatement replays the whole chain; the closed-form minimiser (what the
+    kernels use) follows it for the first 584 of 606 accepted moves and then keeps the better chi² of the two."""
+    g, spec, st = traj_setup("g17_sphere_q100_posbg_minpack.npz")
+    args = (spec, g["data_q"], g["data_I"], g["data_sigma"], g["data_f_limit"], g["data_x0_limit"], st)
+    res = O.mc_fit(*args, O.ReplayStream(g["stream"]), method="leastsq")
+    assert res.num_iter == int(g["res_num_iter"]) and res.num_moves == int(g["res_num_moves"])
+    np.testing.assert_array_equal(np.array(res.accepted), g["res_accepted"])
+    np.testing.assert_allclose(res.rset, g["res_rset"], rtol=1e-15)
+    np.testing.assert_allclose(res.conval, float(g["res_conval"]), rtol=1e-12)
+    longer = np.concatenate([g["stream"], np.random.RandomState(1).random_sample(20000)])
+    clo = O.mc_fit(*args, O.ReplayStream(longer), method="closed")
+    acc, ref = np.array(clo.accepted), g["res_accepted"]
+    n = min(len(acc), len(ref))
+    first = int(np.nonzero(acc[:n] != ref[:n])[0][0])
+    assert first == 584 and ref[first] < acc[first]           # the reference took a step the exact minimum does not justify
+    assert clo.conval <= 1.0
 
 
 @pytest.mark.parametrize("name", TRAJ)
@@ -97,7 +121,7 @@ TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q5
 def test_g4_replay_trajectories(name, method):
     """Replaying the uniform stream the reference consumed reproduces its accept/reject decisions,
     final parameter set and chi² (leastsq: call-for-call restatement; closed: the kernels' fit)."""
-    if method == "leastsq" and (name in ("g4_sphere_q100_converge.npz",) or name.startswith("g9_") or name.startswith("g14_")):
+    if method == "leastsq" and (name in ("g4_sphere_q100_converge.npz",) or name.startswith("g9_") or name.startswith("g14_") or name.startswith("g17_")):
         pytest.skip("covered by the closed-form run (thousands of leastsq steps are slow)")
     if name == "g9_kho_q512.npz" and not os.environ.get("MCSAS_SLOW_TESTS"):
         pytest.skip("config 5 as named through the QUADPACK oracle takes ~10 min: set MCSAS_SLOW_TESTS=1 "
@@ -114,6 +138,11 @@ def test_g4_replay_trajectories(name, method):
     rtol = 1e-12 if method == "leastsq" else 1e-9
     if "posbg" in name and method == "closed":
         rtol = 1e-5
+    if name == "g17_sphere_q100_posbg_converge.npz" and method == "closed":
+        # the reference's LAST fit of this chain ran into MINPACK's maxfev next to the |b| kink and reports a chi² 0.4 % above the
+        # minimum of the very same parameter set (leastsq restatement: 1e-12); the closed form finds the minimum
+        assert float(g["res_conval"]) * (1 - 1e-2) < res.conval <= float(g["res_conval"]) * (1 + 1e-9)
+        return
     np.testing.assert_allclose(res.conval, float(g["res_conval"]), rtol=rtol)
     # (atol: scale * model + background crosses zero on the worm data file, whose intensity spans 9 decades)
     np.testing.assert_allclose(res.fit, g["res_fit"], rtol=1e-6, atol=1e-12 * np.abs(g["res_fit"]).max())
@@ -263,7 +292,7 @@ def test_g8_uncertainty_floor_and_rebin(tag):
 # ----------------------------------------------------------------------------- the C restatement (oracle/c)
 C_TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q512_fixed.npz",
           "g4_sphere_q100_nobg.npz", "g4_sphere_q100_posbg.npz", "g4_sphere_q100_frommin.npz",
-          "g14_sphere_q512_long.npz", "g14_sphere_q512_converge.npz"]
+          "g14_sphere_q512_long.npz", "g14_sphere_q512_converge.npz", "g17_sphere_q100_posbg_converge.npz"]
 
 
 @pytest.mark.parametrize("name", C_TRAJ)
@@ -280,6 +309,9 @@ def test_c_oracle_replays_reference_trajectories(name):
     assert r.num_iter[0] == int(g["res_num_iter"]) and r.num_moves[0] == int(g["res_num_moves"])
     np.testing.assert_array_equal(r.accepted[0, :r.num_moves[0]], g["res_accepted"])
     np.testing.assert_allclose(r.contribs[:, 0, 0], g["res_rset"][:, 0], rtol=1e-15)
+    if name == "g17_sphere_q100_posbg_converge.npz":           # (the reference's last fit hit MINPACK's maxfev: see test_g4_replay_trajectories)
+        assert float(g["res_conval"]) * (1 - 1e-2) < r.chisq[0] <= float(g["res_conval"]) * (1 + 1e-9)
+        return
     np.testing.assert_allclose(r.chisq[0], float(g["res_conval"]), rtol=1e-5 if "posbg" in name else 1e-9)
     np.testing.assert_allclose(r.fit[:, 0], g["res_fit"], rtol=1e-6)
 

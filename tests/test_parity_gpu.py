@@ -67,7 +67,10 @@ TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q5
         "g9_cyl_q512.npz", "g9_ellcs_q1024.npz", "g9_kho_q64.npz", "g9_kho_q512.npz",
         # round 3: config 2's shape (512 q x 400) over long budgets — 25 000 fixed steps (62 sweeps over the contributions) and a
         # chain that the reference ends by convergence (criterion 2, 5509 steps)
-        "g14_sphere_q512_long.npz", "g14_sphere_q512_converge.npz"]
+        "g14_sphere_q512_long.npz", "g14_sphere_q512_converge.npz",
+        # round 4: chains the reference ENDS BY CONVERGENCE (criterion 1) for models with an orientation integral (cylinders 6228
+        # steps, core-shell ellipsoids 1887 steps; 100 q x 200 contributions) and with positiveBackground (sphere, criterion 2, 5768 steps)
+        "g17_cyl_q100_converge.npz", "g17_ellcs_q100_converge.npz", "g17_sphere_q100_posbg_converge.npz"]
 
 
 @pytest.mark.parametrize("name", TRAJ)
@@ -101,7 +104,11 @@ def test_replay_trajectories_vs_reference(name, cache, waves):
     assert res.num_moves[0] == int(g["res_num_moves"])
     np.testing.assert_allclose(res.contribs[:, :, 0], g["res_rset"], rtol=1e-12)
     rtol = 1e-5 if "posbg" in name else 1e-7
-    np.testing.assert_allclose(res.chisq[0], float(g["res_conval"]), rtol=rtol)
+    minpack_gave_up = name == "g17_sphere_q100_posbg_converge.npz"      # (its last fit hit maxfev: tests/test_oracle_golden.py)
+    if minpack_gave_up:
+        assert float(g["res_conval"]) * (1 - 1e-2) < res.chisq[0] <= float(g["res_conval"]) * (1 + 1e-9)
+    else:
+        np.testing.assert_allclose(res.chisq[0], float(g["res_conval"]), rtol=rtol)
     if "posbg" in name:
         # (the reference's MINPACK stalls next to the |b| kink of positiveBackground — its chi² is 1e-6 above the minimum; against
         # the closed-form minimiser of the same residual, replayed by the oracle, there is no such slack)
@@ -109,10 +116,34 @@ def test_replay_trajectories_vs_reference(name, cache, waves):
                        O.ReplayStream(g["stream"]), method="closed")
         assert ref.num_moves == res.num_moves[0]
         np.testing.assert_allclose(res.chisq[0], ref.conval, rtol=1e-9)
+        if minpack_gave_up:
+            np.testing.assert_allclose(res.fit[:, 0], ref.fit, rtol=1e-9)
+            np.testing.assert_allclose(res.scaling[0], ref.scaling, rtol=1e-9)
+            return
     # (atol: scale * model + background crosses zero on the worm data file, whose intensity spans 9 decades)
     np.testing.assert_allclose(res.fit[:, 0], g["res_fit"], rtol=1e-6, atol=1e-12 * np.abs(g["res_fit"]).max())
     np.testing.assert_allclose(res.scaling[0], float(g["res_scaling"]), rtol=1e-6)
     assert res.draws[0] == (0 if st.start_from_minimum else ost.n_contrib * spec.n_active) + res.num_iter[0] * spec.n_active
+
+
+@pytest.mark.parametrize("waves", [1, 8, -3])
+def test_positive_background_chain_that_only_minpack_follows(waves):
+    """g17_..._posbg_minpack (see tests/test_oracle_golden.py): the reference's MINPACK decides accepted move 584 of this chain by
+    stopping 1e-6 above the minimum next to the |b| kink.  The kernels minimise in closed form: on the same stream (continued) they
+    are the closed-form oracle decision for decision, to convergence."""
+    g, m, spec, st, ost = traj_setup("g17_sphere_q100_posbg_minpack.npz")
+    if waves == -3:
+        st.exec_mode = engine.EXEC_PIPELINE
+    else:
+        st.waves_per_chain = waves
+    longer = np.concatenate([g["stream"], np.random.RandomState(1).random_sample(20000)])
+    ref = O.mc_fit(spec, g["data_q"], g["data_I"], g["data_sigma"], g["data_f_limit"], g["data_x0_limit"], ost,
+                   O.ReplayStream(longer), method="closed")
+    res = engine.analyse(m.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st, replay=longer[None, :])
+    assert res.num_iter[0] == ref.num_iter and res.num_moves[0] == ref.num_moves and res.converged[0] == 1
+    np.testing.assert_allclose(res.contribs[:, :, 0], ref.rset, rtol=1e-12)
+    np.testing.assert_allclose(res.chisq[0], ref.conval, rtol=1e-9)
+    assert res.num_iter[0] != int(g["res_num_iter"])          # (documented: not the reference's count)
 
 
 @pytest.mark.parametrize("waves", [1, 8, -3])
@@ -237,6 +268,67 @@ def test_quickstart_acceptance_free_running():
     # the fit itself: mean over the repetitions against the reference's mean curve
     np.testing.assert_allclose(res["fitMeasValMean"], g["fitMean"], rtol=0.02)
 
+
+
+
+def _heavy_free_setup(tag):
+    g = load("g16_%s_free.npz" % tag)
+    model = str(g["spec_model"])
+    extra = {}
+    if model == "cyl_aspect":
+        extra = dict(sld=float(g["spec_sld"]), intDiv=float(g["spec_int_div"]))
+    if model == "ellcs":
+        extra = dict(eta_c=float(g["spec_eta_c"]), eta_s=float(g["spec_eta_s"]), eta_sol=float(g["spec_eta_sol"]),
+                     intDiv=float(g["spec_int_div"]))
+    m, spec = make_models(model, g["spec_lo"], g["spec_hi"], [int(x) for x in g["spec_gen"]], **extra)
+    return g, m, spec
+
+
+@pytest.mark.parametrize("tag,reps", [("cyl", 24), ("ellcs", 24), ("kho", 12)])
+def test_heavy_models_free_running_vs_the_reference_calc(tag, reps):
+    """McSAS.calc() end to end and free-running for the models with an orientation / contour integral (mcsas.py:191-285 +
+    :445-615), against the reference's own free run of the same workload (fixtures g16_*, oracle/make_golden.py
+    gen_free_running_heavy: cylinders and core-shell ellipsoids 100 q x 200 contributions x 8 repetitions to criterion 1 on curves
+    of their own model, the worm-like chain on testdata/sasfit_kho-1-10-1000.dat 64 bins x 64 contributions x 3 repetitions):
+    every repetition here reaches the criterion, the mean number of iterations is the reference's within a factor, and every
+    configured histogram (one per active parameter) agrees bin by bin within the two runs' standard errors; total volume fraction
+    and the distribution mean (Moments.fields[0], [2]) within a few per cent."""
+    import os
+    from helpers import G as golden
+    if not os.path.exists(os.path.join(golden, "g16_%s_free.npz" % tag)):
+        pytest.skip("fixture g16_%s_free.npz not generated (the worm-like chain takes the reference hours)" % tag)
+    g, m, _ = _heavy_free_setup(tag)
+    crit, ref_reps = float(g["crit"]), int(g["reps"])
+    hists = []
+    for k in range(int(g["n_hist"])):
+        pre = "h%d_" % k
+        p = getattr(m, str(g[pre + "param"]))
+        h = mcsas_amd.Histogram(p, float(g[pre + "lo"]), float(g[pre + "hi"]), binCount=int(g[pre + "nbin"]),
+                                xscale=str(g[pre + "xscale"]), yweight=str(g[pre + "yweight"]))
+        p.histograms().append(h)
+        hists.append((pre, h))
+    algo = mcsas_amd.McSAS(seed=77)
+    algo.numContribs.setValue(int(g["n_contrib"])); algo.numReps.setValue(reps)
+    algo.convergenceCriterion.setValue(crit); algo.maxIterations.setValue(float(g["max_iter"]))
+    algo.model = m
+    algo.data = mcsas_amd.SASData(g["data_q"], g["data_I"], g["data_sigma"], f_limit=g["data_f_limit"])
+    algo.calc()
+    res = algo.result[0]
+    assert res["contribs"].shape == (int(g["n_contrib"]), len(g["spec_lo"]), reps)
+    assert (algo.details.chisq <= crit).all() and (algo.details.converged == 1).all()
+    assert 0.5 < res["numIter"] / float(g["numIter"]) < 2.0
+    for pre, h in hists:
+        np.testing.assert_allclose(h.xLowerEdge, g[pre + "edges"], rtol=1e-14)
+        ours, ours_se = np.asarray(h.bins.mean), np.asarray(h.bins.std) / np.sqrt(float(reps))
+        ref, ref_se = g[pre + "bins_mean"], g[pre + "bins_std"] / np.sqrt(float(ref_reps))
+        se = np.sqrt(ours_se**2 + ref_se**2) + 0.01 * ref.max()
+        z = (ours - ref) / se
+        # (the numpy oracle run free on the device's Philox streams — which the kernels reproduce chain for chain — gives
+        # |z| <= 0.93, rms 0.52 for the cylinders, tools/g16_calibration.py)
+        assert np.abs(z).max() < 5.0 and np.sqrt(np.mean(z**2)) < 2.0, (pre, z)
+        mo = np.asarray(h.moments.fields, dtype=float)
+        np.testing.assert_allclose(mo[[0, 2]], g[pre + "moments"][[0, 2]], rtol=0.05 if tag != "kho" else 0.25)
+    np.testing.assert_allclose(res["fitMeasValMean"], g["fitMean"], rtol=0.05)
 
 
 @pytest.mark.parametrize("mode", [engine.EXEC_PIPELINE, engine.EXEC_WAVE, engine.EXEC_WORKGROUP])
@@ -1276,3 +1368,26 @@ def test_analyse_many_and_overlapped_series_equal_one_after_the_other():
     for uid in sa:
         for (ka, ma), (kb, mb) in zip(sa[uid], sb[uid]):
             assert ka == kb and np.array_equal(np.array(ma, dtype=float), np.array(mb, dtype=float))
+
+
+def test_bench_collective_path_runs_on_rccl(tmp_path):
+    """bench.py as a fresh child process under torch.distributed.run (one rank: this box has one GPU) with MCSAS_BENCH_FORCE_DIST=1:
+    init_process_group("nccl", device_id=...), the packed all-gather of the results on the device (mcsas_amd/dist.py
+    gather_results) and the all-reduce of the timings have executed on RCCL; the gathered arrays are the rank's own results."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dump = os.path.join(str(tmp_path), "forced.npz")
+    env = dict(os.environ, MCSAS_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MCSAS_BENCH_DRY", "MCSAS_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--launches-per-step", "2",
+           "--mc-steps", "2000", "--no-cpu-baseline", "--no-convergence-run", "--no-configs", "--no-series", "--dump", dump]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["ranks_seen"] == 1 and line["value"] > 1e6
+    gm = line["gather_ms"]
+    assert gm["backend"] == "nccl" and gm["ranks"] == 1 and gm["first"] > 0 and gm["steady"] > 0
+    a = np.load(dump)
+    assert a["contribs"].shape == (50, 400, 1) and a["fit"].shape == (50, 512) and np.isfinite(a["chisq"]).all()
+    assert (a["chisq"] > 0).all() and (a["contribs"] > 0).all()
