@@ -12,20 +12,32 @@
 
 namespace mcsas {
 
-template <int M, int QPL, bool CACHE>
-__global__ __launch_bounds__(64, (QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1) void chain_wave_kernel(const ChainArgs a) {
+// WPB = wavefronts (chains) per workgroup.  1: a workgroup is one chain (few chains: they spread over every SIMD of the chip).
+// 4 (thousands of chains, rows without an integral, up to 512 q): four chains share one copy of the tables in LDS — with a copy
+// per wave (16 KB at 512 q) the LDS holds ten waves per CU whatever the registers say — and the step is written for 128 registers
+// (the proposal's row is kept, d = new - old is formed again from the reloaded `old` row on the 6 % of steps that are accepted;
+// q slots evaluated two at a time), so that FOUR waves share a SIMD: a step is one long dependent chain (row -> three sums ->
+// DPP reduction -> fit -> decision), which a SIMD hides only with other waves.  Same operations per chain: same results.
+template <int M, int QPL, bool CACHE> constexpr int wave_min_occupancy(int wpb) {
+    return wpb >= 4 ? 4 : ((QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1);
+}
+template <int M, int QPL, bool CACHE, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB))) void chain_wave_kernel(const ChainArgs a) {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const int rep = blockIdx.x;
+    constexpr bool LEAN = WPB >= 4;                        // the 128-register form of the step (see above)
+    constexpr int RGW = LEAN ? 2 : MCSAS_ROW_GROUP;
+    const int lane = threadIdx.x & 63;
+    const int rep = blockIdx.x * WPB + (threadIdx.x >> 6);
     const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad;
     double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
-    for (int i = lane; i < qpad; i += WAVE) {
+    for (int i = threadIdx.x; i < qpad; i += WAVE * WPB) {
         const double qq = a.q[i];
         lq[i] = qq; lw[i] = a.w[i]; lwI[i] = a.wI[i]; lq3[i] = 1.0 / (qq * qq * qq);
     }
     const QTables qt = make_qtables<M>(a.model, lq, lq3, tab);
-    Contrib<M>::fill_table(a.model, tab, lane, WAVE);
+    Contrib<M>::fill_table(a.model, tab, threadIdx.x, WAVE * WPB);
     __syncthreads();
+    if (rep >= a.n_reps) return;                           // (the last workgroup's spare waves; no barrier below)
 
     double *rset = a.rset + (size_t)rep * N * P;
     double *cache = CACHE ? a.cache + (size_t)rep * a.cache_rows * qpad : nullptr;
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(64, (QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1) void 
             for (int i = 0; i < cnt; ++i) {
                 const Contrib<M> c = mine.bcast(__builtin_amdgcn_readfirstlane(i));
                 double it[QPL];
-                RowEval<M, QPL>::run(c, qt, lane, it);
+                RowEval<M, QPL>::template run<RGW>(c, qt, lane, it);
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
                     ft[j] += it[j];
@@ -141,10 +153,10 @@ __global__ __launch_bounds__(64, (QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1) void 
                     for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) orow[p] = (p < P) ? rset[(size_t)ri * P + p] : 0.;
                     Contrib<M> cold;
                     cold.prepare(a.model, orow);
-                    RowEval<M, QPL>::run(cold, qt, lane, test);
+                    RowEval<M, QPL>::template run<RGW>(cold, qt, lane, test);
                 }
                 double s1 = 0., s2 = 0., s3 = 0.;
-                RowEval<M, QPL>::run(cnew, qt, lane, inew);
+                RowEval<M, QPL>::template run<RGW>(cnew, qt, lane, inew);
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
                     // mcsas.py:367 has (ft - old) + new; every execution mode here adds the fp64 difference d = new - old
@@ -153,6 +165,7 @@ __global__ __launch_bounds__(64, (QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1) void 
                     test[j] = ft[j] + (inew[j] - test[j]);
                     double wt = lw[lane + WAVE * j] * test[j];
                     s1 += wt; s2 = fma(wt, test[j], s2); s3 = fma(lwI[lane + WAVE * j], test[j], s3);
+                    if constexpr (LEAN && CACHE) asm volatile("" :: "v"(test[j]));   // (test is not kept: see the accepted branch)
                 }
                 wave_sum3(s1, s2, s3);
                 // s1 = Σ w C, s2 = Σ w C², s3 = Σ w I C of the candidate (mcsas.py:376)
@@ -165,10 +178,24 @@ __global__ __launch_bounds__(64, (QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1) void 
                 if (num * num > (S - X) * den) {                                   // mcsas.py:379-390
                     X = S - num * num / den;
                     cur.chi2 = X / nqd;
+                    if constexpr (LEAN && CACHE) {
+                        // the candidate's ft again from the `old` row (an L1 / L2 hit: it was read a row evaluation ago) — the same
+                        // operation on the same numbers as above, so the same bits — instead of eight doubles held across every step
+                        const double *orow = cache + (size_t)ri * qpad + lane;
+                        double od[QPL];
 #pragma unroll
-                    for (int j = 0; j < QPL; ++j) {
-                        ft[j] = test[j];
-                        if (CACHE) cache[(size_t)ri * qpad + lane + WAVE * j] = inew[j];
+                        for (int j = 0; j < QPL; ++j) od[j] = orow[WAVE * j];
+#pragma unroll
+                        for (int j = 0; j < QPL; ++j) {
+                            ft[j] = ft[j] + (inew[j] - od[j]);
+                            cache[(size_t)ri * qpad + lane + WAVE * j] = inew[j];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < QPL; ++j) {
+                            ft[j] = test[j];
+                            if (CACHE) cache[(size_t)ri * qpad + lane + WAVE * j] = inew[j];
+                        }
                     }
 #pragma unroll
                     for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)

@@ -465,14 +465,20 @@ struct DeviceGuard {
 // entries instead of one scattered 4 KB / 64 KB page per array (and a plan costs 6 hipMalloc calls instead of 25).
 // Memory that plans give back is kept for the next plan (per device, exact size): a series of analyses — McSAS.calc() per data
 // set, one plan each — otherwise pays ~3 ms of hipFree / hipHostFree per plan for 3.4 ms of kernels, plus as much for stream and
-// pinned-memory creation.  Up to MCSAS_CACHE_BYTES of device memory stay parked; mcsas_hip_release_cached_memory() frees them.
+// pinned-memory creation.  Up to 4 GiB of device memory (MCSAS_HIP_CACHE_MB in the environment: another cap, 0 = none) stay parked;
+// mcsas_hip_release_cached_memory() frees them.
 struct MemCache {
     std::mutex mu;
     std::multimap<std::pair<int, size_t>, void *> dev;        // (device, bytes) -> free device blocks
     std::multimap<std::pair<unsigned, size_t>, void *> host;  // (flags, bytes) -> free pinned blocks
     std::map<int, hipStream_t> copy_stream;                   // per device: the non-blocking stream results come back on
     size_t dev_bytes = 0;
-    static constexpr size_t MCSAS_CACHE_BYTES = (size_t)4 << 30;
+    // how much device memory may stay parked per process: 4 GiB, or MCSAS_HIP_CACHE_MB from the environment (0: nothing is kept —
+    // for hosts whose own allocator (torch's, say) should see every byte this library is not using)
+    size_t cap_bytes = (size_t)4 << 30;
+    MemCache() {
+        if (const char *e = getenv("MCSAS_HIP_CACHE_MB")) { char *end = nullptr; const long long mb = strtoll(e, &end, 10); if (end != e && mb >= 0) cap_bytes = (size_t)mb << 20; }
+    }
 };
 static MemCache &mem_cache() { static MemCache c; return c; }
 static hipError_t cached_dev_malloc(void **p, size_t n) {
@@ -496,7 +502,7 @@ static hipError_t cached_dev_malloc(void **p, size_t n) {
 static void cached_dev_free(void *p, size_t n, int d) {
     MemCache &c = mem_cache();
     std::lock_guard<std::mutex> lk(c.mu);
-    if (c.dev_bytes + n <= MemCache::MCSAS_CACHE_BYTES) { c.dev.insert({{d, n}, p}); c.dev_bytes += n; }
+    if (c.dev_bytes + n <= c.cap_bytes) { c.dev.insert({{d, n}, p}); c.dev_bytes += n; }
     else hipFree(p);
 }
 static hipError_t cached_host_malloc(void **p, size_t n, unsigned flags) {
@@ -512,7 +518,7 @@ static void cached_host_free(void *p, size_t n, unsigned flags) {
     if (!p) return;
     MemCache &c = mem_cache();
     std::lock_guard<std::mutex> lk(c.mu);
-    if (c.host.size() < 64) c.host.insert({{flags, n}, p});
+    if (c.cap_bytes > 0 && c.host.size() < 64) c.host.insert({{flags, n}, p});
     else hipHostFree(p);
 }
 static hipError_t cached_copy_stream(hipStream_t *st) {
@@ -585,6 +591,7 @@ struct mcsas_plan {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t stream = nullptr;
     bool launched = false;
+    bool enqueue_failed = false;        // a launch returned an error after it had put work on `stream`: nothing marks where that work ends
     double last_ms = 0.;
     int64_t last_steps = 0;
     WgGeom wg{};
@@ -699,6 +706,12 @@ static void *wg_kernel_for(int model, int qpl) {
 extern "C" void mcsas_hip_plan_destroy(mcsas_plan *pl) {
     if (!pl) return;
     // (nothing of this plan may still be running when its memory goes back to the cache: hipFree used to wait, the cache does not)
+    if (pl->enqueue_failed) {           // a launch that failed half-way left kernels behind no event of ours: wait for the stream (and the device)
+        (void)hipSetDevice(pl->dev);
+        (void)hipStreamSynchronize(pl->stream);
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+    }
     if (pl->launched && pl->ev1) (void)hipEventSynchronize(pl->ev1);
     for (int k = 0; k < MCSAS_PLAN_SLOTS; ++k)
         if (k != pl->cur_slot && pl->slots[k].made && pl->slots[k].launched && pl->slots[k].ev1) (void)hipEventSynchronize(pl->slots[k].ev1);
@@ -1094,11 +1107,23 @@ extern "C" int mcsas_hip_plan_launch_slot(mcsas_plan *pl, void *hip_stream, int3
         if (rcs) return rcs;
     }
     hipStream_t st = (hipStream_t)hip_stream;
+    // The slots of a plan share its workspaces (row cache, chain records, window buffers, argument block): an analysis must not start
+    // before the other slots' analyses have ended.  On one stream that is the stream's order; launched on ANOTHER stream this one waits
+    // for their end events (a no-op when they are complete).  This slot's own previous analysis must be over before its pinned
+    // argument block is rewritten.
+    for (int k = 0; k < MCSAS_PLAN_SLOTS; ++k)
+        if (k != pl->cur_slot && pl->slots[k].made && pl->slots[k].launched && pl->slots[k].ev1) HIPCHK(hipStreamWaitEvent(st, pl->slots[k].ev1, 0));
+    if (pl->launched && pl->ev1) HIPCHK(hipEventSynchronize(pl->ev1));
     *pl->h_stop = (pl->prob.stop && *pl->prob.stop) ? 1 : 0;
+    pl->stream = st;
+    struct FailGuard {                                    // (any error return below leaves work on `st` that no end event covers)
+        mcsas_plan *pl; bool ok = false;
+        ~FailGuard() { if (!ok) pl->enqueue_failed = true; }
+    } guard{pl};
     if (pl->mode == MCSAS_EXEC_PIPELINE) {
         int rc = pipeline_launch(pl, st);
         if (rc) return rc;
-        pl->stream = st; pl->launched = true;
+        pl->launched = true; guard.ok = true;
         return MCSAS_OK;
     }
     void *kargs[] = {(void *)&pl->args};
@@ -1111,7 +1136,7 @@ extern "C" int mcsas_hip_plan_launch_slot(mcsas_plan *pl, void *hip_stream, int3
         HIPCHK(hipModuleLaunchKernel(pl->plugin_fn, grid.x, 1, 1, wgm ? WAVE * pl->waves : WAVE, 1, 1, (unsigned)pl->lds_bytes, st,
                                      wgm ? kargs2 : kargs, nullptr));
         HIPCHK(hipEventRecord(pl->ev1, st));
-        pl->stream = st; pl->launched = true;
+        pl->launched = true; guard.ok = true;
         return MCSAS_OK;
     }
     if (pl->mode == MCSAS_EXEC_WAVE) {
@@ -1138,7 +1163,7 @@ extern "C" int mcsas_hip_plan_launch_slot(mcsas_plan *pl, void *hip_stream, int3
         HIPCHK(hipLaunchKernel(fn, grid, block, kargs2, pl->lds_bytes, st));
     }
     HIPCHK(hipEventRecord(pl->ev1, st));
-    pl->stream = st; pl->launched = true;
+    pl->launched = true; guard.ok = true;
     return MCSAS_OK;
 }
 

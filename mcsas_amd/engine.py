@@ -203,19 +203,35 @@ def analyse_many(problems, streams=2):
     if not problems:
         return []
     lib = _lib.load(tuning=bool(problems[0]["st"].debug_flags))
-    hs = []
-    for _ in range(max(1, min(streams, len(problems)))):
-        h = C.c_void_p()
-        check(lib.mcsas_hip_stream_create(C.c_int32(problems[0]["st"].device), C.byref(h)), lib)
-        hs.append(h)
-    out, pending = [None] * len(problems), []
+    per_dev = {}                                              # device ordinal -> the stream handles created on THAT device
+
+    def stream_for(dev, k):
+        hs = per_dev.setdefault(dev, [])
+        if len(hs) < max(1, streams):
+            h = C.c_void_p()
+            check(lib.mcsas_hip_stream_create(C.c_int32(dev), C.byref(h)), lib)
+            hs.append(h)
+        return hs[k % len(hs)]
+
+    def direct(pr):
+        return analyse(pr["model"], pr["q"], pr["intensity"], pr["sigma"], pr["st"], pr.get("replay"), pr.get("stop"), pr.get("smear"))
+
+    out, pending, launched = [None] * len(problems), [], {}
     try:
         for i, pr in enumerate(problems):
-            while len(pending) >= 2 * len(hs):
+            st = pr["st"]
+            # what a plan cannot do goes through mcsas_hip_analyse at its place in the sequence: a model with no active parameter
+            # (one contribution, nothing to fit: mcsas.py:198-199) and a device list (the library shards the repetitions itself)
+            if pr["model"].n_active == 0 or st.devices:
+                out[i] = direct(pr)
+                continue
+            cap = 2 * max(1, streams)
+            while len(pending) >= cap:
                 j, pl = pending.pop(0)
                 out[j] = pl.fetch(); pl.close()
-            pl = Plan(pr["model"], pr["q"], pr["intensity"], pr["sigma"], pr["st"], pr.get("replay"), pr.get("stop"), pr.get("smear"))
-            pl.launch(stream=hs[i % len(hs)].value)
+            pl = Plan(pr["model"], pr["q"], pr["intensity"], pr["sigma"], st, pr.get("replay"), pr.get("stop"), pr.get("smear"))
+            k = launched.get(st.device, 0); launched[st.device] = k + 1
+            pl.launch(stream=stream_for(st.device, k).value)
             pending.append((i, pl))
         while pending:
             j, pl = pending.pop(0)
@@ -223,8 +239,9 @@ def analyse_many(problems, streams=2):
     finally:
         for _, pl in pending:
             pl.close()
-        for h in hs:
-            lib.mcsas_hip_stream_destroy(h)
+        for hs in per_dev.values():
+            for h in hs:
+                lib.mcsas_hip_stream_destroy(h)
     return out
 
 

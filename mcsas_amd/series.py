@@ -19,6 +19,7 @@ def run_series(algo, datasets, keys=None, replays=None, overlap=False):
     results, series = [], OrderedDict()
     chains = None
     if overlap and algo.model.paramCount():
+        algo.stop = False                                    # calc() resets it per data set (mcsas.py:152); here once, for the batch
         # the Monte-Carlo part of every data set first, side by side on the device (engine.analyse_many: the data sets' analyses are
         # independent); the loop below then only stores each result and takes its histograms — the same numbers as one after the other
         from . import engine
@@ -33,7 +34,8 @@ def run_series(algo, datasets, keys=None, replays=None, overlap=False):
         if chains is None:
             algo.calc(replay=None if replays is None else replays[i])
         else:
-            algo.result = []; algo.stop = False
+            # (McSAS.stop is left as the analyses saw it: _store tells "stop pressed" from "criterion not reached" by it)
+            algo.result = []
             algo._store(chains[i])
             if len(algo.result):
                 algo.histogram()

@@ -560,6 +560,36 @@ def test_edge_shapes_all_modes_agree_with_oracle(nq, n, steps, reps):
     assert ran >= 2                                    # auto always runs, and wavefront or q-split workgroup mode
 
 
+@pytest.mark.parametrize("case", ["si_units", "huge_counts", "tiny_volumes"])
+def test_extreme_unit_scalings_all_modes_agree_with_oracle(case):
+    """The decision of a step compares products of fit sums (num² den' > num'² den): their exponent range is what the data's and the
+    model's units make it.  Intensities in SI-like units (1e-30), detector counts of 1e+40 with matching uncertainties, and
+    sub-nanometre spheres with compensationExponent 1 (volume^2 weights of 1e-59) under large uncertainties: every execution mode
+    still takes the oracle's decisions — nothing underflows to "0 > 0 is never accepted"."""
+    q, I, sig = _synthetic(100)
+    lo, hi, comp = np.pi / q.max(), np.pi / q.min(), 0.6666666
+    if case == "si_units":
+        I, sig = I * 1e-30, sig * 1e-30
+    elif case == "huge_counts":
+        I, sig = I * 1e40, sig * 1e40
+    else:
+        q = q * 10.0; lo, hi, comp = 1e-10, 1e-9, 1.0
+        sig = sig * 1e6
+    m, spec = make_models("sphere", [lo], [hi])
+    n, steps, reps = 60, 600, 3
+    ost = O.Settings(n_contrib=n, n_reps=1, max_iter=steps, conv_crit=1e-9, comp_exp=comp)
+    ref = [O.mc_fit(spec, q, I, sig, [I.min(), I.max()], [q.min(), q.max()], ost, O.PhiloxStream(5, r), method="closed")
+           for r in range(reps)]
+    assert all(r.num_moves > 20 for r in ref)
+    for mode in (engine.EXEC_WAVE, engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE):
+        st = engine.Settings(n_contrib=n, n_reps=reps, max_iter=steps, conv_crit=1e-9, max_retries=0, seed=5, exec_mode=mode, comp_exp=comp)
+        res = engine.analyse(m.setup(), q, I, sig, st)
+        for r in range(reps):
+            assert res.num_iter[r] == ref[r].num_iter and res.num_moves[r] == ref[r].num_moves, (mode, r)
+            np.testing.assert_allclose(res.contribs[:, :, r], ref[r].rset, rtol=1e-12)
+            np.testing.assert_allclose(res.chisq[r], ref[r].conval, rtol=1e-7)
+
+
 @pytest.mark.parametrize("mode", [engine.EXEC_WAVE, engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE])
 def test_stop_word_is_honoured_in_every_mode(mode):
     import ctypes
@@ -1368,6 +1398,24 @@ def test_analyse_many_and_overlapped_series_equal_one_after_the_other():
     for uid in sa:
         for (ka, ma), (kb, mb) in zip(sa[uid], sb[uid]):
             assert ka == kb and np.array_equal(np.array(ma, dtype=float), np.array(mb, dtype=float))
+    # what a plan cannot do is run through mcsas_hip_analyse at its place in the sequence: a model with parameters but none active
+    # (one contribution, nothing to fit: mcsas.py:198-199) and a device list; a stopped series says "stop pressed"
+    q, I, sig = _synthetic(100)
+    fixed = mcsas_amd.Sphere(); fixed.radius.setValue(2.5e-8); fixed.radius.setActive(False)
+    mixed = [(fixed.setup(), q, I, sig, engine.Settings(n_contrib=1, n_reps=1)), probs[0],
+             (probs[0][0], q, I, sig, engine.Settings(n_contrib=120, n_reps=5, max_iter=900, conv_crit=1e-9, max_retries=0, seed=131, devices=(0, 0)))]
+    got = engine.analyse_many(mixed)
+    for pr, g_ in zip(mixed, got):
+        one = engine.analyse(*pr)
+        for name in ("contribs", "fit", "chisq", "num_iter"):
+            np.testing.assert_array_equal(getattr(g_, name), getattr(one, name), err_msg=name)
+    outs = []
+    for overlap in (False, True):
+        algo = mcsas_amd.McSAS(seed=9)
+        algo.model = fixed
+        outs.append(mcsas_amd.run_series(algo, [mcsas_amd.SASData(q, I, sig), mcsas_amd.SASData(q, 2 * I, sig)], overlap=overlap)[0])
+    for a, b in zip(*outs):
+        assert a["contribs"].shape == (1, 0, 1) and np.array_equal(a["fitMeasValMean"], b["fitMeasValMean"])
 
 
 def test_bench_collective_path_runs_on_rccl(tmp_path):
