@@ -654,17 +654,29 @@ class ClockSampler(object):
 
     def __init__(self, dev_index):
         import glob
-        self.freq, self.power = None, None
+        self.freq, self.power, self.how = None, None, None
         cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
         cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
-        if cards:
-            c = cards[min(dev_index if dev_index >= 0 else 0, len(cards) - 1)]
-            self.freq = os.path.join(c, "freq1_input")
-            for name in ("power1_average", "power1_input"):
-                if os.path.exists(os.path.join(c, name)):
-                    self.power = os.path.join(c, name)
-                    break
+        pick = None
+        try:                                                 # the card whose PCI address is the HIP device's
+            import torch
+            pr = torch.cuda.get_device_properties(max(dev_index, 0))
+            addr = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            for c in cards:
+                if addr in os.path.realpath(os.path.join(c, "device")):
+                    pick, self.how = c, "pci " + addr + "0"
+        except Exception:
+            pass
+        self.cards = cards if pick is None else [pick]       # (no match: sample every card, report the busiest)
         self.samples, self._stop, self._th = [], False, None
+
+    def _paths(self, c):
+        p = None
+        for name in ("power1_average", "power1_input"):
+            if os.path.exists(os.path.join(c, name)):
+                p = os.path.join(c, name)
+                break
+        return os.path.join(c, "freq1_input"), p
 
     @staticmethod
     def _read(path):
@@ -674,15 +686,14 @@ class ClockSampler(object):
             return None
 
     def _loop(self):
+        paths = [self._paths(c) for c in self.cards]
         while not self._stop:
-            f = self._read(self.freq) if self.freq else None
-            p = self._read(self.power) if self.power else None
-            self.samples.append((time.perf_counter(), f, p))
+            self.samples.append([(self._read(f), self._read(p) if p else None) for f, p in paths])
             time.sleep(0.05)
 
     def __enter__(self):
         import threading
-        if self.freq:
+        if self.cards:
             self._th = threading.Thread(target=self._loop, daemon=True); self._th.start()
         return self
 
@@ -692,12 +703,19 @@ class ClockSampler(object):
             self._th.join()
 
     def summary(self):
-        f = np.array([s[1] for s in self.samples if s[1] is not None]) / 1e6          # Hz -> MHz
-        p = np.array([s[2] for s in self.samples if s[2] is not None]) / 1e6          # uW -> W
-        if not len(f):
-            return {"available": False, "note": "no hwmon freq1_input for the card: clocks not sampled"}
+        if not self.samples:
+            return {"available": False, "note": "no hwmon freq1_input under /sys/class/drm: clocks not sampled"}
+        best = None
+        for i, c in enumerate(self.cards):
+            f = np.array([s[i][0] for s in self.samples if s[i][0] is not None]) / 1e6          # Hz -> MHz
+            p = np.array([s[i][1] for s in self.samples if s[i][1] is not None]) / 1e6          # uW -> W
+            if len(f) and (best is None or (len(p) and np.median(p) > best[3])):
+                best = (c, f, p, float(np.median(p)) if len(p) else 0.0)
+        if best is None:
+            return {"available": False, "note": "hwmon entries unreadable"}
+        c, f, p, _ = best
         out = {"available": True, "samples": int(len(f)), "sclk_mhz": {"min": float(f.min()), "median": float(np.median(f)), "max": float(f.max())},
-               "source": self.freq}
+               "source": os.path.join(c, "freq1_input"), "card_chosen_by": self.how or "highest median power of %d cards sampled" % len(self.cards)}
         if len(p):
             out["power_w"] = {"min": float(p.min()), "median": float(np.median(p)), "max": float(p.max())}
         return out
