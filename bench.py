@@ -400,6 +400,9 @@ def main():
     barrier()
     del launch_ms[:]
     state["mc"] = 0
+    sampler = ClockSampler(dev_index) if (not dry and rank == 0) else None
+    if sampler:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for k in range(args.steps):
         for _ in range(lps):
@@ -407,6 +410,8 @@ def main():
     drain()
     barrier()
     dt = time.perf_counter() - t0
+    if sampler:
+        sampler.__exit__()
     dt_local = dt
     mc_total, res = state["mc"], state["res"]
     gather_last()
@@ -497,6 +502,8 @@ def main():
                               {"n": int(len(lm)), "mean": float(lm.mean()), "min": float(lm.min()), "max": float(lm.max()),
                                "note": "= launch_ms: one stream, an analysis' events bracket its own kernels only"},
         }
+        if sampler:
+            out["clocks"] = sampler.summary()
         if state["gather_ms"]:
             gm = state["gather_ms"]
             out["gather_ms"] = {"first": gm[0], "steady": float(np.min(gm[1:])) if len(gm) > 1 else None, "backend": backend, "ranks": world,
@@ -718,6 +725,10 @@ class ClockSampler(object):
                "source": os.path.join(c, "freq1_input"), "card_chosen_by": self.how or "highest median power of %d cards sampled" % len(self.cards)}
         if len(p):
             out["power_w"] = {"min": float(p.min()), "median": float(np.median(p)), "max": float(p.max())}
+        for name in ("power1_cap", "power1_cap_max", "power1_cap_default"):
+            v = self._read(os.path.join(c, name))
+            if v is not None:
+                out[name + "_w"] = v / 1e6
         return out
 
 
@@ -793,15 +804,16 @@ def other_configs(dev_index, seconds=1.0):
         plan = engine.Plan(setup, wl["q"], wl["I"], wl["sigma"], st)
         plan.reseed(76, 0); plan.launch(); plan.fetch(want_arrays=False)          # warm-up
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        steps, ms, n, res = 0, [], 0, None
-        while True:
-            plan.reseed(77 + n, 0); plan.launch(); res = plan.fetch()
-            steps += plan.total_steps; ms.append(plan.last_ms); n += 1
-            if time.perf_counter() - t0 >= seconds:
-                break
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        with ClockSampler(dev_index) as cs1:
+            t0 = time.perf_counter()
+            steps, ms, n, res = 0, [], 0, None
+            while True:
+                plan.reseed(77 + n, 0); plan.launch(); res = plan.fetch()
+                steps += plan.total_steps; ms.append(plan.last_ms); n += 1
+                if time.perf_counter() - t0 >= seconds:
+                    break
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
         info = plan.info
         rate = steps / dt
         # ... and the same with a second plan on a stream of its own, two result slots each (the main workload's scheme): the
@@ -845,7 +857,7 @@ def other_configs(dev_index, seconds=1.0):
              "streams": 2, "result_slots": 2,
              "one_stream": {"value": rate_one, "timed_region_s": dt, "launches": n, "mc_steps": steps,
                             "launch_ms": {"min": float(np.min(ms)), "median": float(np.median(ms)), "max": float(np.max(ms))},
-                            "init_ms": init, "value_excl_init": steps / max(dev_s - n * init * 1e-3, 1e-9)},
+                            "init_ms": init, "value_excl_init": steps / max(dev_s - n * init * 1e-3, 1e-9), "clocks": cs1.summary()},
              "exec_mode": info["exec_mode"], "window": info["window"], "final_chisq_median": float(np.median(res.chisq)),
              "chisq_of_truth": wl["chisq_of_truth"],
              "ff_points_per_s": rate * pts, "ff_points_per_mc_step": pts}

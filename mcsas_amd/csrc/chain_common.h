@@ -54,7 +54,8 @@ struct ChainArgs {
     int32_t  rep_offset, pad0;
     const double *replay;              // [n_reps][replay_len] or null
     int64_t  replay_len;
-    const int32_t *stop_flag;          // host-mapped word, polled
+    const int32_t *stop_flag;          // McSAS.stop as the kernels see it: a word in HOST memory (pinned, mapped)
+    int32_t *stop_relay;               // device memory: [0] the relayed stop word, [2..3] (uint64) time of the last look at the host word (stop_requested)
     // per-chain state / outputs in HBM
     double  *rset;                     // [n_reps][n_contrib][n_active]
     double  *cache;                    // [n_reps][cache_rows][qpad] per-contribution intensities (or null)
@@ -62,6 +63,34 @@ struct ChainArgs {
     double  *fit;                      // [n_reps][qpad]
     ChainOut *out;                     // [n_reps]
 };
+
+// McSAS.stop (mcsas.py:357: polled once per step).  The caller's word lives in host memory, and a read of it crosses the host link:
+// microseconds each, served one at a time — 8192 chains looking every 64 steps were measured to spend HALF of a launch queued
+// up on those reads (3.7e8 instead of 7.5e8 steps/s, whatever the q count).  So the chains look at a word in device memory (an L2
+// hit) and whoever comes by more than 100 us after the last look at the host word (one compare-and-swap on a device time stamp
+// elects it) reads the host word and relays it: a few thousand host reads per second whatever the number of chains, and a stop
+// is seen by every chain within its next 64 steps + 100 us.
+__device__ __forceinline__ bool stop_requested(const ChainArgs &a) {
+    if (!a.stop_flag) return false;
+    // one lane asks, the wave gets one answer (every lane of a wave must leave its loop at the same step)
+    const int first = (int)__builtin_ctzll(__ballot(1));
+    int r = 0;
+    if ((int)(threadIdx.x & 63) == first) {
+        if (__hip_atomic_load(a.stop_relay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) r = 1;
+        else {
+            unsigned long long *stamp = reinterpret_cast<unsigned long long *>(a.stop_relay + 2);
+            const unsigned long long now = wall_clock64() | 1ull;     // 100 MHz; never the "nobody has looked yet" value 0
+            unsigned long long last = __hip_atomic_load(stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((last == 0ull || now - last >= 10000ull) &&
+                __hip_atomic_compare_exchange_strong(stamp, &last, now, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
+                __hip_atomic_load(a.stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+                __hip_atomic_store(a.stop_relay, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                r = 1;
+            }
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(r) != 0;
+}
 
 struct FitResult { double A, b, chi2; };
 

@@ -131,9 +131,7 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
         bool running = (N > 1);
         while (running) {
             if (!(cur.chi2 > a.conv_crit) || !(num_iter < a.max_iter)) break;
-            if (a.stop_flag && __hip_atomic_load(a.stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
-                stopped = 1; break;
-            }
+            if (stop_requested(a)) { stopped = 1; break; }   // (wave-uniform: one lane's answer, broadcast by the scalar unit)
             // proposals for the next 64 steps, one per lane: generateParameters() draws P uniforms
             // per step in parameter order (mcsas.py:358)
             double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};

@@ -287,8 +287,7 @@ __device__ __forceinline__ void wg_scanner(const ChainArgs &a, const WgGeom &g, 
             if (win > 0 && live) {
                 const int sb = buf ^ 1;                 // window win-1
                 bool touched = false;
-                if (a.stop_flag && (win & 255) == 1 &&
-                    __hip_atomic_load(a.stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) stopped = 1;
+                if ((win & 15) == 1 && stop_requested(a)) stopped = 1;
                 int ri = (int)(((win - 1) * K) % N);
                 const int64_t budget = a.max_iter - num_iter;
                 const int kmax = budget < K ? (int)budget : K;

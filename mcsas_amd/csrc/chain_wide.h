@@ -134,7 +134,7 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void chain_wide_kernel(const C
             // McSAS.stop: one thread looks, everybody acts on what it saw (a wave of its own could see the word change
             // between two waves' reads and leave the others at the next barrier)
             if (a.stop_flag) {
-                if (tid == 0) *stop_word = __hip_atomic_load(a.stop_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (tid == 0) *stop_word = stop_requested(a) ? 1 : 0;
                 __syncthreads();
                 if (*stop_word) { stopped = 1; break; }
             }

@@ -589,7 +589,8 @@ struct mcsas_plan {
     double *d_q = nullptr, *d_w = nullptr, *d_wI = nullptr, *d_I = nullptr, *d_q3inv = nullptr;
     double *d_rset = nullptr, *d_cache = nullptr, *d_fit = nullptr, *d_replay = nullptr;
     ChainOut *d_out = nullptr;
-    int32_t *h_stop = nullptr;          // pinned + mapped: the kernels poll it
+    int32_t *h_stop = nullptr;          // pinned + mapped: McSAS.stop as the kernels see it
+    int32_t *d_stop_relay = nullptr;    // device memory, 16 bytes: the relayed stop word and the time stamp of the last look at h_stop (chain_common.h: stop_requested)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipStream_t stream = nullptr;
     bool launched = false;
@@ -935,6 +936,15 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
         cache_rows = (int)N + 2 * pl->pipe.g.kb;
     }
+    // The chains' row blocks must not all start at the same offset modulo the memory system's interleave: with N = 400 rows of
+    // 4 KB a chain's block is 50 x 32 KB, every chain's row r sits at the same place in the channel pattern, and thousands of
+    // chains walking their rows in step queue up on the same channels (measured: identical launches of 8192 chains at 3.7e8 or
+    // 7.5e8 steps/s depending on whether the chains happened to run in step).  Spare rows make the block an odd number of rows.
+    {
+        int pad_rows = (cache_rows & 1) ? 0 : 1;
+        if (const char *e = getenv("MCSAS_HIP_CACHE_PAD_ROWS")) pad_rows = atoi(e) < 0 ? 0 : atoi(e);     // (measurement knob)
+        cache_rows += pad_rows;
+    }
     size_t cache_bytes = sizeof(double) * R * (size_t)cache_rows * qpad;
     int use_cache = p->cache_intensities;
     if (use_cache < 0 || mode != MCSAS_EXEC_WAVE || wide_q) {
@@ -974,6 +984,8 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
     a.seed = p->seed; a.rep_offset = p->rep_offset; a.pad0 = p->reserved0;   // (0 in the release library: checked above)
     a.replay = pl->d_replay; a.replay_len = p->replay_len;
     a.stop_flag = d_stop;
+    PCHK(pl->pool.get(&pl->d_stop_relay, 16));
+    a.stop_relay = pl->d_stop_relay;
     a.rset = pl->d_rset; a.cache = pl->d_cache; a.cache_rows = cache_rows; a.fit = pl->d_fit; a.out = pl->d_out;
 
     if (mode == MCSAS_EXEC_WAVE) {
@@ -1135,6 +1147,7 @@ extern "C" int mcsas_hip_plan_launch_slot(mcsas_plan *pl, void *hip_stream, int3
     if (pl->launched && pl->ev1) HIPCHK(hipEventSynchronize(pl->ev1));
     *pl->h_stop = (pl->prob.stop && *pl->prob.stop) ? 1 : 0;
     pl->stream = st;
+    if (pl->mode != MCSAS_EXEC_PIPELINE) HIPCHK(hipMemsetAsync(pl->d_stop_relay, 0, 16, st));   // (the pipeline's ticks get McSAS.stop as a kernel argument)
     struct FailGuard {                                    // (any error return below leaves work on `st` that no end event covers)
         mcsas_plan *pl; bool ok = false;
         ~FailGuard() { if (!ok) pl->enqueue_failed = true; }
