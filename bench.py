@@ -732,10 +732,10 @@ class ClockSampler(object):
         return out
 
 
-def many_chains(wl, dev_index, reps=8192, mc_steps=2000, seconds=1.5):
+def many_chains(wl, dev_index, reps=8192, mc_steps=20000, seconds=1.5):
     """The kernel north_star describes literally — one wavefront per chain, thousands of chains: Sphere 512 q x 400 contributions,
-    8192 repetitions, MCSAS_EXEC_WAVE, back-to-back launches of 2000 steps per chain sustained over >= `seconds`, clocks and power
-    sampled beside it."""
+    8192 repetitions, MCSAS_EXEC_WAVE, back-to-back launches of 20 000 steps per chain (the headline workload's budget per launch;
+    chain initialisation included) sustained over >= `seconds`, clocks and power sampled beside it."""
     import torch
     from mcsas_amd import engine
     setup = wl["model"].setup()

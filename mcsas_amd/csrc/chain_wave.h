@@ -12,42 +12,20 @@
 
 namespace mcsas {
 
-constexpr int MCSAS_WAVE_WPB = 8;        // chains per workgroup of the many-chains variant: two workgroups per CU = four waves per SIMD
-
-// WPB = wavefronts (chains) per workgroup.  1: a workgroup is one chain (few chains: they spread over every SIMD of the chip).
-// 4 (thousands of chains, rows without an integral, up to 512 q): four chains share one copy of the tables in LDS — with a copy
-// per wave (16 KB at 512 q) the LDS holds ten waves per CU whatever the registers say — and the step is written for 128 registers
-// (the proposal's row is kept, d = new - old is formed again from the reloaded `old` row on the 6 % of steps that are accepted;
-// q slots evaluated two at a time), so that FOUR waves share a SIMD: a step is one long dependent chain (row -> three sums ->
-// DPP reduction -> fit -> decision), which a SIMD hides only with other waves.  Same operations per chain: same results.
-template <int M, int QPL, bool CACHE> constexpr int wave_min_occupancy(int wpb) {
-    return wpb >= 4 ? 4 : ((QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1);
-}
-template <int M, int QPL, bool CACHE, int WPB = 1>
-__global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB))) void chain_wave_kernel(const ChainArgs a) {
+template <int M, int QPL, bool CACHE>
+__global__ __launch_bounds__(64, (QPL < 8 || (QPL == 8 && CACHE)) ? 2 : 1) void chain_wave_kernel(const ChainArgs a) {
     extern __shared__ double lds[];
-    constexpr bool LEAN = WPB >= 4;                        // the 128-register form of the step (see above)
-    constexpr int RGW = LEAN ? 2 : MCSAS_ROW_GROUP;
-    const int lane = threadIdx.x & 63;
-    const int rep = blockIdx.x * WPB + (threadIdx.x >> 6);
+    const int lane = threadIdx.x;
+    const int rep = blockIdx.x;
     const int N = a.n_contrib, P = a.model.n_active, qpad = a.qpad;
     double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
-    for (int i = threadIdx.x; i < qpad; i += WAVE * WPB) {
+    for (int i = lane; i < qpad; i += WAVE) {
         const double qq = a.q[i];
         lq[i] = qq; lw[i] = a.w[i]; lwI[i] = a.wI[i]; lq3[i] = 1.0 / (qq * qq * qq);
     }
     const QTables qt = make_qtables<M>(a.model, lq, lq3, tab);
-    Contrib<M>::fill_table(a.model, tab, threadIdx.x, WAVE * WPB);
+    Contrib<M>::fill_table(a.model, tab, lane, WAVE);
     __syncthreads();
-    if (rep >= a.n_reps) return;                           // (the last workgroup's spare waves; no barrier below)
-    // LEAN: the 64 proposals a wave prepares at a time (their Contrib records and parameter values) are parked in LDS, field-major
-    // (conflict-free to write, a broadcast to read), instead of in 20 registers per lane read with v_readlane
-    constexpr int CON = (int)(sizeof(Contrib<M>) / 8), PREC = CON + MCSAS_MAX_ACTIVE;
-    static_assert(sizeof(Contrib<M>) % 8 == 0, "Contrib record");
-    double *prec = LEAN ? tab + Contrib<M>::table_doubles(a.model.int_div) + (size_t)(threadIdx.x >> 6) * (PREC * WAVE + qpad) : nullptr;
-    // ... and so is the chain's running model intensity ft (read once per step like the weights beside it, written on the 6 % of
-    // steps that are accepted): sixteen registers per lane that the row evaluation gets instead
-    double *lft = LEAN ? prec + PREC * WAVE : nullptr;
 
     double *rset = a.rset + (size_t)rep * N * P;
     double *cache = CACHE ? a.cache + (size_t)rep * a.cache_rows * qpad : nullptr;
@@ -57,11 +35,7 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
     uint64_t draw_pos = 0;                 // uniforms consumed so far by this rep (all attempts)
     const uint64_t t_start = wall_clock64();
 
-    double ft_reg[LEAN ? 1 : QPL];
-    auto ftr = [&](int j) -> double & {                    // ft of q slot j: a register, or the wave's LDS row (LEAN)
-        if constexpr (LEAN) return lft[lane + WAVE * j];
-        else return ft_reg[j];
-    };
+    double ft[QPL];
     FitResult cur{1.0, 0.0, 0.0};
     int64_t num_iter = 0, num_moves = 0, total_steps = 0;
     int attempts = 0, converged = 0, stopped = 0;
@@ -71,7 +45,7 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
         // ------------------------------------------------------------ initial parameter set
         // generateParameters(N): N draws per active parameter, parameter-major (scatteringmodel.py:117-127)
 #pragma unroll
-        for (int j = 0; j < QPL; ++j) ftr(j) = 0.;
+        for (int j = 0; j < QPL; ++j) ft[j] = 0.;
         for (int n0 = 0; n0 < N; n0 += WAVE) {
             const int n = n0 + lane;
             double row[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
@@ -97,10 +71,10 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
             for (int i = 0; i < cnt; ++i) {
                 const Contrib<M> c = mine.bcast(__builtin_amdgcn_readfirstlane(i));
                 double it[QPL];
-                RowEval<M, QPL>::template run<RGW>(c, qt, lane, it);
+                RowEval<M, QPL>::run(c, qt, lane, it);
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
-                    ftr(j) += it[j];
+                    ft[j] += it[j];
                     if (CACHE) cache[(size_t)(n0 + i) * qpad + lane + WAVE * j] = it[j];
                 }
             }
@@ -112,8 +86,8 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
             double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
-                const double f = ftr(j), wt = lw[lane + WAVE * j] * f;
-                s1 += wt; s2 = fma(wt, f, s2); s3 = fma(lwI[lane + WAVE * j], f, s3);
+                double wt = lw[lane + WAVE * j] * ft[j];
+                s1 += wt; s2 = fma(wt, ft[j], s2); s3 = fma(lwI[lane + WAVE * j], ft[j], s3);
             }
             wave_sum3(s1, s2, s3);
             cur = solve_fit(a, s1, s2, s3);
@@ -131,7 +105,7 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
         bool running = (N > 1);
         while (running) {
             if (!(cur.chi2 > a.conv_crit) || !(num_iter < a.max_iter)) break;
-            if (stop_requested(a)) { stopped = 1; break; }   // (wave-uniform: one lane's answer, broadcast by the scalar unit)
+            if (stop_requested(a)) { stopped = 1; break; }   // (one answer per wave: chain_common.h)
             // proposals for the next 64 steps, one per lane: generateParameters() draws P uniforms
             // per step in parameter order (mcsas.py:358)
             double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
@@ -146,35 +120,15 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
                 }
             Contrib<M> prop;
             prop.prepare(a.model, prow);
-            if constexpr (LEAN) {
-                double tmp[CON];
-                __builtin_memcpy(tmp, &prop, sizeof(Contrib<M>));
-#pragma unroll
-                for (int f = 0; f < CON; ++f) prec[f * WAVE + lane] = tmp[f];
-#pragma unroll
-                for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) prec[(CON + p) * WAVE + lane] = prow[p];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (wave-private region: its own writes, in order)
-            }
 
             int k = 0;
             for (; k < WAVE; ++k) {
                 if (!(cur.chi2 > a.conv_crit) || !(num_iter < a.max_iter)) { running = false; break; }
                 const int kk = __builtin_amdgcn_readfirstlane(k);
-                Contrib<M> cnew;
-                if constexpr (LEAN) {
-                    double tmp[CON];
-#pragma unroll
-                    for (int f = 0; f < CON; ++f) tmp[f] = readlane_f64(prec[f * WAVE + kk], 0);   // uniform address: one value, into SGPRs
-                    __builtin_memcpy(&cnew, tmp, sizeof(Contrib<M>));
-                } else {
-                    cnew = prop.bcast(kk);
-                }
+                const Contrib<M> cnew = prop.bcast(kk);
                 if (__builtin_amdgcn_readlane(povf, kk)) overflow = 1;
                 double inew[QPL], test[QPL];
-                if constexpr (LEAN && CACHE) {
-                    // the `old` row is asked for BEHIND the evaluation of the new one (below): eight doubles held across the
-                    // evaluation are eight the evaluation does not have, and the three other waves of the SIMD cover the wait
-                } else if (CACHE) {
+                if (CACHE) {
                     const double *orow = cache + (size_t)ri * qpad + lane;
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) test[j] = orow[WAVE * j];
@@ -185,24 +139,18 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
                     for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) orow[p] = (p < P) ? rset[(size_t)ri * P + p] : 0.;
                     Contrib<M> cold;
                     cold.prepare(a.model, orow);
-                    RowEval<M, QPL>::template run<RGW>(cold, qt, lane, test);
+                    RowEval<M, QPL>::run(cold, qt, lane, test);
                 }
                 double s1 = 0., s2 = 0., s3 = 0.;
-                RowEval<M, QPL>::template run<RGW>(cnew, qt, lane, inew);
-                if constexpr (LEAN && CACHE) {
-                    const double *orow = cache + (size_t)ri * qpad + lane;
-#pragma unroll
-                    for (int j = 0; j < QPL; ++j) test[j] = orow[WAVE * j];
-                }
+                RowEval<M, QPL>::run(cnew, qt, lane, inew);
 #pragma unroll
                 for (int j = 0; j < QPL; ++j) {
                     // mcsas.py:367 has (ft - old) + new; every execution mode here adds the fp64 difference d = new - old
                     // instead (the workgroup and pipeline kernels carry d rows), so that ft is the SAME number in all
                     // three modes — at most one ulp per accepted move away from the reference's order
-                    test[j] = ftr(j) + (inew[j] - test[j]);
+                    test[j] = ft[j] + (inew[j] - test[j]);
                     double wt = lw[lane + WAVE * j] * test[j];
                     s1 += wt; s2 = fma(wt, test[j], s2); s3 = fma(lwI[lane + WAVE * j], test[j], s3);
-                    if constexpr (LEAN && CACHE) asm volatile("" :: "v"(test[j]));   // (test is not kept: see the accepted branch)
                 }
                 wave_sum3(s1, s2, s3);
                 // s1 = Σ w C, s2 = Σ w C², s3 = Σ w I C of the candidate (mcsas.py:376)
@@ -215,31 +163,15 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
                 if (num * num > (S - X) * den) {                                   // mcsas.py:379-390
                     X = S - num * num / den;
                     cur.chi2 = X / nqd;
-                    if constexpr (LEAN && CACHE) {
-                        // the candidate's ft again from the `old` row (an L1 / L2 hit: it was read a row evaluation ago) — the same
-                        // operation on the same numbers as above, so the same bits — instead of eight doubles held across every step
-                        const double *orow = cache + (size_t)ri * qpad + lane;
-                        double od[QPL];
 #pragma unroll
-                        for (int j = 0; j < QPL; ++j) od[j] = orow[WAVE * j];
-#pragma unroll
-                        for (int j = 0; j < QPL; ++j) {
-                            ftr(j) = ftr(j) + (inew[j] - od[j]);
-                            cache[(size_t)ri * qpad + lane + WAVE * j] = inew[j];
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < QPL; ++j) {
-                            ftr(j) = test[j];
-                            if (CACHE) cache[(size_t)ri * qpad + lane + WAVE * j] = inew[j];
-                        }
+                    for (int j = 0; j < QPL; ++j) {
+                        ft[j] = test[j];
+                        if (CACHE) cache[(size_t)ri * qpad + lane + WAVE * j] = inew[j];
                     }
 #pragma unroll
                     for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
                         if (p < P) {
-                            double val;
-                            if constexpr (LEAN) val = prec[(CON + p) * WAVE + kk];
-                            else val = readlane_f64(prow[p], kk);
+                            double val = readlane_f64(prow[p], kk);
                             if (lane == 0) rset[(size_t)ri * P + p] = val;
                         }
                     if (!CACHE) __threadfence_block();   // rset[ri] is re-read by every lane N steps later
@@ -257,8 +189,8 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
             double s1 = 0., s2 = 0., s3 = 0.;
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
-                const double f = ftr(j), wt = lw[lane + WAVE * j] * f;
-                s1 += wt; s2 = fma(wt, f, s2); s3 = fma(lwI[lane + WAVE * j], f, s3);
+                double wt = lw[lane + WAVE * j] * ft[j];
+                s1 += wt; s2 = fma(wt, ft[j], s2); s3 = fma(lwI[lane + WAVE * j], ft[j], s3);
             }
             wave_sum3(s1, s2, s3);
             cur = solve_fit(a, s1, s2, s3);
@@ -267,7 +199,7 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
 #pragma unroll
             for (int j = 0; j < QPL; ++j) {
                 const int i = lane + WAVE * j;
-                double r = a.I[i] - (ftr(j) * cur.A + cur.b);
+                double r = a.I[i] - (ft[j] * cur.A + cur.b);
                 rs += lw[i] * r * r;
             }
             cur.chi2 = wave_sum(rs) / (double)a.nq;
@@ -279,7 +211,7 @@ __global__ __launch_bounds__(64 * WPB, (wave_min_occupancy<M, QPL, CACHE>(WPB)))
     // ---------------------------------------------------------------- outputs (mcsas.py:428-439)
 #pragma unroll
     for (int j = 0; j < QPL; ++j)
-        a.fit[(size_t)rep * qpad + lane + WAVE * j] = ftr(j) * cur.A + cur.b;      // ifinal*sc[0]+sc[1]
+        a.fit[(size_t)rep * qpad + lane + WAVE * j] = ft[j] * cur.A + cur.b;      // ifinal*sc[0]+sc[1]
     overflow = __any(overflow);
     if (lane == 0) {
         ChainOut o;

@@ -11,19 +11,6 @@ using namespace mcsas;
 template <int QPL> static void *pick(bool cache) {
     return cache ? (void *)chain_wave_kernel<MCSAS_M, QPL, true> : (void *)chain_wave_kernel<MCSAS_M, QPL, false>;
 }
-// MCSAS_WAVE_WPB chains per workgroup (thousands of chains; rows without an integral, cached rows, 64 .. 512 q-points): chain_wave.h
-void *CAT(mcsas_wave4_kernel_m, MCSAS_M)(int qpl) {
-    if constexpr (Contrib<MCSAS_M>::ROW_CLASS == 0) {
-        switch (qpl) {
-            case 1: return (void *)chain_wave_kernel<MCSAS_M, 1, true, MCSAS_WAVE_WPB>;
-            case 2: return (void *)chain_wave_kernel<MCSAS_M, 2, true, MCSAS_WAVE_WPB>;
-            case 4: return (void *)chain_wave_kernel<MCSAS_M, 4, true, MCSAS_WAVE_WPB>;
-            case 8: return (void *)chain_wave_kernel<MCSAS_M, 8, true, MCSAS_WAVE_WPB>;
-            default: return nullptr;
-        }
-    }
-    return nullptr;
-}
 void *CAT(mcsas_wave_kernel_m, MCSAS_M)(int qpl, bool cache) {
     switch (qpl) {
         case 1: return pick<1>(cache);

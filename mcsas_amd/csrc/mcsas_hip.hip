@@ -22,7 +22,6 @@
 #include "chain_wg.h"   // WgGeom / wg_geometry only; the kernels are instantiated in kern_*.hip
 #include "chain_pipe.h" // PipeArgs / pipe_geometry only
 #include "chain_wide.h" // WIDE_* constants only
-#include "chain_wave.h" // MCSAS_WAVE_WPB only; the kernels are instantiated in kern_wave.hip
 #include "auto_table.h" // measured rates of the execution modes (tools/make_auto_table.py)
 #include "model_list.h" // MCSAS_FOR_MODELS: the built-in models
 
@@ -366,15 +365,15 @@ extern "C" const char *mcsas_hip_plugin_log(void) { return g_plugin_log.c_str();
 
 // ------------------------------------------------------------------------------ host helpers
 // what the host needs to know about a model, read off its Contrib<M> (models.h) — no per-model code below this table
-struct ModelTraits { int int_div_param, rowtab, row_class; bool can_smear; int (*table_doubles)(int); int contrib_doubles; };
+struct ModelTraits { int int_div_param, rowtab, row_class; bool can_smear; int (*table_doubles)(int); };
 static ModelTraits model_traits(int model_id) {
-#define TRAITS_OF(m) {Contrib<m>::INT_DIV_PARAM, Contrib<m>::ROWTAB, Contrib<m>::ROW_CLASS, Contrib<m>::CAN_SMEAR, &Contrib<m>::table_doubles, (int)(sizeof(Contrib<m>) / 8)},
+#define TRAITS_OF(m) {Contrib<m>::INT_DIV_PARAM, Contrib<m>::ROWTAB, Contrib<m>::ROW_CLASS, Contrib<m>::CAN_SMEAR, &Contrib<m>::table_doubles},
     static const ModelTraits builtin[] = {MCSAS_FOR_MODELS(TRAITS_OF)};
 #undef TRAITS_OF
     static_assert(sizeof builtin / sizeof builtin[0] == MCSAS_MODEL_COUNT, "model_list.h and include/mcsas_hip.h disagree");
     if (model_id >= 0 && model_id < MCSAS_MODEL_COUNT) return builtin[model_id];
     const Plugin *pg = plugin_of(model_id);                                           // plugin_model.h
-    return ModelTraits{-1, 0, pg ? pg->row_class : 0, pg ? pg->can_smear : false, [](int) { return 0; }, 0};
+    return ModelTraits{-1, 0, pg ? pg->row_class : 0, pg ? pg->can_smear : false, [](int) { return 0; }};
 }
 static int model_int_div(const mcsas_problem *p) {
     const int i = model_traits(p->model_id).int_div_param;
@@ -583,7 +582,6 @@ struct mcsas_plan {
     ChainArgs args;
     SmearDev smear;                     // device copy of the smearing tables (empty when off)
     int qpl = 0, waves = 1, use_cache = 1, dev = 0;
-    int wave_wpb = 1;                   // wavefront mode: chains per workgroup (1, or MCSAS_WAVE_WPB with thousands of chains: chain_wave.h)
     bool wide = false;                  // more than 1024 q-points, one workgroup per chain with the q-points split over its waves (chain_wide.h)
     size_t lds_bytes = 0;
     double *d_q = nullptr, *d_w = nullptr, *d_wI = nullptr, *d_I = nullptr, *d_q3inv = nullptr;
@@ -667,7 +665,7 @@ static int plan_activate_slot(mcsas_plan *pl, int k) {
 }
 
 // kernel lookups, one translation unit per model (kern_wave.hip / kern_wg.hip)
-#define DECL_K(m) void *mcsas_wave_kernel_m##m(int, bool); void *mcsas_wave4_kernel_m##m(int); void *mcsas_wg_kernel_m##m(int); void *mcsas_wide_kernel_m##m(int); void *mcsas_pipe_tick_kernel_m##m(int);
+#define DECL_K(m) void *mcsas_wave_kernel_m##m(int, bool); void *mcsas_wg_kernel_m##m(int); void *mcsas_wide_kernel_m##m(int); void *mcsas_pipe_tick_kernel_m##m(int);
 MCSAS_FOR_MODELS(DECL_K)
 #undef DECL_K
 void *mcsas_pipe_reset_kernel();
@@ -684,14 +682,6 @@ static void *pipe_tick_kernel_for(int model, int qpl) {
 static void *wave_kernel_for(int model, int qpl, bool cache) {
     switch (model) {
 #define CASE_K(m) case m: return mcsas_wave_kernel_m##m(qpl, cache);
-        MCSAS_FOR_MODELS(CASE_K)
-#undef CASE_K
-        default: return nullptr;
-    }
-}
-static void *wave_many_kernel_for(int model, int qpl) {      // MCSAS_WAVE_WPB chains per workgroup (chain_wave.h), or null
-    switch (model) {
-#define CASE_K(m) case m: return mcsas_wave4_kernel_m##m(qpl);
         MCSAS_FOR_MODELS(CASE_K)
 #undef CASE_K
         default: return nullptr;
@@ -990,15 +980,6 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
 
     if (mode == MCSAS_EXEC_WAVE) {
         pl->lds_bytes = sizeof(double) * (4 * (size_t)qpad + TABD(1));
-        // thousands of chains of a model without an integral: MCSAS_WAVE_WPB chains per workgroup on one copy of the tables, the
-        // step in 128 registers with the proposals and ft parked in LDS -> four waves per SIMD (chain_wave.h).  From 8 chains per
-        // CU on, i.e. where that many single-wave workgroups would not spread any wider either.
-        if (!plugin && use_cache && p->smear_nk <= 0 && R >= (size_t)MCSAS_WAVE_WPB * (size_t)n_cus && wave_many_kernel_for(p->model_id, qpl) &&
-            !(MCSAS_TUNE_BITS(a) & (1 << 21))) {   // (tuning bit 21: single-wave workgroups whatever the chain count)
-            const size_t per_wave = (size_t)qpad + (size_t)(model_traits(p->model_id).contrib_doubles + MCSAS_MAX_ACTIVE) * WAVE;
-            const size_t need = sizeof(double) * (4 * (size_t)qpad + TABD(1) + MCSAS_WAVE_WPB * per_wave);
-            if (need <= 80 * 1024) { pl->wave_wpb = MCSAS_WAVE_WPB; pl->lds_bytes = need; }
-        }
         if (plugin) {
             rc = plugin_wave_function(p->model_id, qpl, use_cache != 0, &pl->plugin_fn);     // (compiled on first use of this q count)
             if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
@@ -1172,14 +1153,8 @@ extern "C" int mcsas_hip_plan_launch_slot(mcsas_plan *pl, void *hip_stream, int3
         return MCSAS_OK;
     }
     if (pl->mode == MCSAS_EXEC_WAVE) {
-        if (pl->wave_wpb > 1) {
-            fn = wave_many_kernel_for(pl->prob.model_id, pl->qpl);
-            grid = dim3((pl->prob.n_reps + pl->wave_wpb - 1) / pl->wave_wpb);
-            block = dim3(WAVE * pl->wave_wpb);
-        } else {
-            fn = wave_kernel_for(pl->prob.model_id, pl->qpl, pl->use_cache);
-            block = dim3(WAVE);
-        }
+        fn = wave_kernel_for(pl->prob.model_id, pl->qpl, pl->use_cache);
+        block = dim3(WAVE);
     } else if (pl->wide) {
         fn = wide_kernel_for(pl->prob.model_id, pl->qpl);
         block = dim3(WAVE * pl->waves);

@@ -794,7 +794,6 @@ __device__ __forceinline__ double row_cost(const Contrib<M> &c, const double *lq
 // are worked out once per row into the wave's LDS scratch, which leaves two multiplies, the branch-free
 // sincos (and J1) and two FMAs per (q, k).
 template <int M, int QPL> struct RowEval {
-    template <int RGREQ = MCSAS_ROW_GROUP>                     // (see the sphere's specialisation; ignored here)
     static __device__ __forceinline__ void run(const Contrib<M> &c, const QTables &t, int lane, double (&out)[QPL]) {
         if constexpr (Contrib<M>::CAN_SMEAR) {
             if (t.smear_nk > 0) {
@@ -832,9 +831,6 @@ __device__ __forceinline__ QTables make_qtables(const ModelArgs &a, const double
     return QTables{q, q3inv, tab, rt, a.smear_locs_t, a.smear_cw, Contrib<M>::CAN_SMEAR ? a.smear_nk : 0, a.smear_stride};
 }
 template <int QPL> struct RowEval<MCSAS_MODEL_SPHERE, QPL> {
-    // RGREQ: q slots per lane evaluated in one interleaved group (default MCSAS_ROW_GROUP; a kernel that runs four waves per
-    // SIMD in 128 registers asks for two — the other waves fill the pipe).  The operations per point do not depend on it.
-    template <int RGREQ = MCSAS_ROW_GROUP>
     static __device__ __forceinline__ void run(const Contrib<MCSAS_MODEL_SPHERE> &c, const QTables &t, int lane,
                                                double (&out)[QPL]) {
         if (t.smear_nk > 0) {
@@ -849,7 +845,7 @@ template <int QPL> struct RowEval<MCSAS_MODEL_SPHERE, QPL> {
             // per instruction instead of ~4)
             // (four at a time: four interleaved chains keep the pipe busy as well as eight do and leave the registers of the
             // other four to the caller — the pipeline's producer carries Gram accumulators across this call)
-            constexpr int RG = QPL < RGREQ ? QPL : RGREQ;
+            constexpr int RG = QPL < MCSAS_ROW_GROUP ? QPL : MCSAS_ROW_GROUP;
 #pragma unroll
             for (int j0 = 0; j0 < QPL; j0 += RG) {
                 double qq[RG], q3[RG], o[RG];

@@ -225,28 +225,35 @@ class Moments(object):
                 "skew", "skewStd", "kurtosis", "kurtosisStd")
 
     def __init__(self, contribs, paramIndex, valueRange, fraction):
-        vals = contribs[:, paramIndex, :]
-        numReps = vals.shape[1]
+        numReps = contribs.shape[2]
+        # (repetition-major copies: the ordered sums below then run along contiguous rows)
+        vals = np.ascontiguousarray(contribs[:, paramIndex, :].T)
+        fraction = np.ascontiguousarray(np.asarray(fraction).T)
         lo, hi = min(valueRange), max(valueRange)
-        val = np.zeros(numReps); mu = np.zeros(numReps); var = np.zeros(numReps)
-        skw = np.zeros(numReps); krt = np.zeros(numReps)
-        for ri in range(numReps):
-            valid = (vals[:, ri] > lo) * (vals[:, ri] < hi)
-            if not valid.any():
-                continue
-            rset, frac = vals[valid, ri], fraction[valid, ri]
-            ssum = lambda x: np.cumsum(x)[-1]                 # adds in the order of the reference's builtin sum()
-            tot = ssum(frac)
-            val[ri] = tot
-            mu[ri] = ssum(rset * frac)
-            if 0 != tot:
-                mu[ri] /= tot
-            var[ri] = ssum((rset - mu[ri])**2 * frac) / tot
-            sigma = np.sqrt(abs(var[ri]))
-            if (tot * sigma) == 0.0:
-                continue
-            skw[ri] = ssum((rset - mu[ri])**3 * frac) / (tot * sigma**3)
-            krt[ri] = ssum((rset - mu[ri])**4 * frac) / (tot * sigma**4)
+        # All repetitions at once.  The reference sums the valid contributions of a repetition with the builtin sum(), i.e. in
+        # contribution order; a cumulative sum down the contribution axis with the invalid entries replaced by +0.0 adds the
+        # same numbers in the same order (x + 0.0 == x bit for bit).  The powers are products (d*d*d, (d*d)*(d*d)): numpy's
+        # `**3` / `**4` go through pow(), whose last bit differs between its scalar and its SIMD array path on one machine already
+        # (and 40 000 calls of it were most of histogram()'s time); the moments are compared at 1e-6.
+        valid = (vals > lo) & (vals < hi)
+        anyv = valid.any(axis=1)
+
+        def ssum(x):
+            return np.cumsum(np.where(valid, x, 0.0), axis=1)[:, -1] if x.shape[1] else np.zeros(numReps)
+
+        with np.errstate(invalid='ignore', divide='ignore', over='ignore'):
+            tot = ssum(fraction)
+            mu = ssum(vals * fraction)
+            mu = np.where(tot != 0, mu / np.where(tot != 0, tot, 1.0), mu)
+            dev = vals - mu[:, None]
+            dev2 = dev * dev
+            var = ssum(dev2 * fraction) / tot
+            sigma = np.sqrt(np.abs(var))
+            ok = anyv & ((tot * sigma) != 0.0) & np.isfinite(tot * sigma)
+            sigma2 = sigma * sigma
+            skw = np.where(ok, ssum(dev2 * dev * fraction) / (tot * (sigma2 * sigma)), 0.0)
+            krt = np.where(ok, ssum(dev2 * dev2 * fraction) / (tot * (sigma2 * sigma2)), 0.0)
+        val = np.where(anyv, tot, 0.0); mu = np.where(anyv, mu, 0.0); var = np.where(anyv, var, 0.0)
         ddof = 1 if numReps > 1 else 0
         self.total = (val.mean(), val.std(ddof=ddof)); self.mean = (mu.mean(), mu.std(ddof=ddof))
         self.variance = (var.mean(), var.std(ddof=ddof)); self.skew = (skw.mean(), skw.std(ddof=ddof))
@@ -325,25 +332,25 @@ class Histogram(object):
         else:
             self.xLowerEdge = np.logspace(np.log10(self.lower), np.log10(self.upper), self.binCount + 1)
         self.xWidth = np.diff(self.xLowerEdge)
-        self.xMean = np.array([self.xLowerEdge[i:i + 2].mean() for i in range(self.binCount)])
+        self.xMean = (self.xLowerEdge[:-1] + self.xLowerEdge[1:]) / 2.0     # (numpy's mean of two: their sum over 2)
 
     def calc(self, contribs, paramIndex, fractions):          # :420-439
         self._setXLowerEdge()
         numContribs, dummy, numReps = contribs.shape
         frac, minReq = fractions[self.yweight]
         # _calcBins/_calcBin (:441-469) for every (bin, repetition) at once.  A contribution with
-        # edge[b] <= x < edge[b+1] belongs to bin b; numpy.add.at accumulates unbuffered and in index order,
-        # i.e. in the order of the reference's builtin sum() over the masked contributions.
+        # edge[b] <= x < edge[b+1] belongs to bin b; numpy.bincount walks its input once, in order, adding weight i to cell
+        # index[i] — with the (contribution, repetition) array flattened row-major a cell's members are added in contribution
+        # order, the order of the reference's builtin sum() over the masked contributions.
         nb = self.binCount
-        par = contribs[:, paramIndex, :]
-        b = np.searchsorted(self.xLowerEdge, par, side='right') - 1
+        par = np.ascontiguousarray(contribs[:, paramIndex, :])
+        b = np.searchsorted(self.xLowerEdge, par.ravel(), side='right').reshape(par.shape) - 1
         inb = (b >= 0) & (b < nb) & (par < self.xLowerEdge[-1])
-        rr = np.broadcast_to(np.arange(numReps)[None, :], par.shape)
-        idx = (b[inb], rr[inb])
-        bins = np.zeros((nb, numReps)); obsSum = np.zeros((nb, numReps)); cnt = np.zeros((nb, numReps))
-        np.add.at(bins, idx, frac[inb])
-        np.add.at(obsSum, idx, minReq[inb])
-        np.add.at(cnt, idx, 1.)
+        cell = (b * numReps + np.arange(numReps)[None, :])[inb]
+        ncell = nb * numReps
+        bins = np.bincount(cell, weights=frac[inb], minlength=ncell)[:ncell].reshape(nb, numReps)
+        obsSum = np.bincount(cell, weights=minReq[inb], minlength=ncell)[:ncell].reshape(nb, numReps)
+        cnt = np.bincount(cell, minlength=ncell)[:ncell].reshape(nb, numReps).astype(float)
         bins[np.isnan(bins)] = 0.
         with np.errstate(invalid='ignore', divide='ignore'):
             allObs = np.where(cnt > 0, obsSum / cnt, 0.)      # mean of the members' visibility limits

@@ -590,38 +590,6 @@ def test_extreme_unit_scalings_all_modes_agree_with_oracle(case):
             np.testing.assert_allclose(res.chisq[r], ref[r].conval, rtol=1e-7)
 
 
-@pytest.mark.parametrize("tag,nq,crit", [("sphere", 512, 140.), ("sphere", 100, 140.), ("gausschain", 64, 1e-9), ("sphcs", 200, 790.),
-                                         ("lmasphere", 256, 66.)])
-def test_many_chains_wave_variant_equals_single_wave_workgroups(tag, nq, crit):
-    """One wavefront per chain with thousands of chains: from 8 chains per CU on the library runs eight chains per workgroup on one
-    copy of the tables, proposals and ft parked in LDS, four waves per SIMD (chain_wave.h, MCSAS_WAVE_WPB).  Same operations per
-    chain: every array equals the single-wave workgroups' (tuning bit 21) bit for bit, retries and a ragged last workgroup
-    included, and the first chains are the oracle's."""
-    q, I, sig = _synthetic(nq)
-    lo, hi = RANDOM_RANGES[tag] if tag != "sphere" else ([np.pi / q.max()], [np.pi / q.min()])
-    m, spec = make_models(tag, lo, hi)
-    n, steps, reps = 48, 260, 2051
-    out = []
-    for flags in (0, 1 << 21):
-        st = engine.Settings(n_contrib=n, n_reps=reps, max_iter=steps, conv_crit=crit, max_retries=1, seed=5, exec_mode=engine.EXEC_WAVE,
-                             debug_flags=flags)
-        if flags == 0:
-            pl = engine.Plan(m.setup(), q, I, sig, st)
-            assert pl.info["exec_mode"] == "wave"
-            pl.close()
-        out.append(engine.analyse(m.setup(), q, I, sig, st))
-    a, b = out
-    for name in ("contribs", "fit", "chisq", "scaling", "background", "num_iter", "num_moves", "attempts", "converged", "draws"):
-        np.testing.assert_array_equal(getattr(a, name), getattr(b, name), err_msg=name)
-    assert a.attempts.max() == 2
-    if crit > 1.:
-        assert 0 < a.converged.sum() < reps                                # (both outcomes and a retry are in the sample)
-    for r in (0, 1, 2050):
-        ref, _ = O.analyse(spec, q, I, sig, [I.min(), I.max()], [q.min(), q.max()], O.Settings(n_contrib=n, n_reps=1, max_iter=steps,
-                           conv_crit=crit, max_retries=1, show_incomplete=True), [O.PhiloxStream(5, r)], method="closed")
-        np.testing.assert_allclose(a.contribs[:, :, r], ref["contribs"][:, :, 0], rtol=1e-12)
-
-
 @pytest.mark.parametrize("mode", [engine.EXEC_WAVE, engine.EXEC_WORKGROUP, engine.EXEC_PIPELINE])
 def test_stop_word_is_honoured_in_every_mode(mode):
     import ctypes
