@@ -246,6 +246,28 @@ int mcsas_hip_observability(const mcsas_problem *problem, const double *contribs
 int mcsas_hip_histogram_prep(const mcsas_problem *problem, const double *contribs, double *scaling,
                              double *vset, double *wset, double *sset, double *min_req_vol);
 
+/* ---- McSAS.histogram(), ALL of it for all repetitions in one call (mcsas.py:445-615) --------------
+ * What mcsas_hip_histogram_prep does, then on the device as well: the volume / number / intensity / surface fractions and
+ * their visibility limits with the per-repetition normalisation (mcsas.py:561-604), and for every configured histogram
+ * (utils/parameter.py:187-538: one per (parameter, range, weighting)) the bins, the mean visibility limit of a bin's
+ * members, the cumulative distribution (Histogram._calcBins / _calcCDF :441-479) and the moments per repetition
+ * (Moments :84-122) — every sum taken over the contributions in contribution order, the order of the reference's
+ * builtin sum().  The means / standard deviations over the repetitions (VectorResult :156-184) are left to the caller.
+ *   specs[h]: param_index = column of contribs; weighting 0 vol, 1 num, 2 int, 3 surf; edges = n_bin + 1 lower bin edges
+ *             (Histogram._setXLowerEdge :349-362, evaluated by the caller so that bin membership is numpy's); lower / upper =
+ *             the histogram's value range (Moments count lower < x < upper).
+ *   scaling[2][n_reps]; fractions[8][n_contrib][n_reps] = vol, num, int, surf fractions, then their visibility limits
+ *   (may be NULL); out = per histogram, one after the other: bins[n_bin][n_reps], obs[n_bin][n_reps] (0 for an empty bin),
+ *   cdf[n_bin][n_reps], moments[5][n_reps] (total, mean, variance, skew, kurtosis).
+ * n_contrib <= 4096 (the contributions of a repetition are staged in LDS): MCSAS_EINVAL beyond, use mcsas_hip_histogram_prep. */
+typedef struct mcsas_histogram_spec {
+    int32_t param_index, weighting, n_bin, reserved;
+    double  lower, upper;
+    const double *edges;
+} mcsas_histogram_spec;
+int mcsas_hip_histogram(const mcsas_problem *problem, const double *contribs, int32_t n_hist,
+                        const mcsas_histogram_spec *specs, double *scaling, double *fractions, double *out);
+
 /* ---- input preparation ----------------------------------------------------------
  * DataObj._prepareUncertainty (dataobj/dataobj.py:204-227): sigma_out = max(sigma_raw, fu_min * I),
  * fu_min * I when sigma_raw is NULL (no uncertainty column), +inf where that is not finite. */

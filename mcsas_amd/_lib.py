@@ -25,7 +25,7 @@ SYMBOLS = (
     "mcsas_hip_plan_launch_slot", "mcsas_hip_plan_fetch_slot",
     "mcsas_hip_plan_last_ms", "mcsas_hip_plan_total_steps", "mcsas_hip_plan_reseed", "mcsas_hip_plan_info",
     "mcsas_hip_plan_destroy", "mcsas_hip_model_calc", "mcsas_hip_bgfit", "mcsas_hip_observability",
-    "mcsas_hip_histogram_prep", "mcsas_hip_prepare_uncertainty", "mcsas_hip_rebin",
+    "mcsas_hip_histogram_prep", "mcsas_hip_histogram", "mcsas_hip_prepare_uncertainty", "mcsas_hip_rebin",
     "mcsas_hip_plugin_compile", "mcsas_hip_plugin_log", "mcsas_hip_release_cached_memory", "mcsas_hip_stream_create", "mcsas_hip_stream_destroy",
     "mcsas_hip_device_count", "mcsas_hip_abi_version", "mcsas_hip_is_tuning_build", "mcsas_hip_last_error",
 )
@@ -33,6 +33,12 @@ SYMBOLS = (
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
+
+
+class HistogramSpec(C.Structure):
+    """mcsas_histogram_spec (include/mcsas_hip.h)."""
+    _fields_ = [("param_index", C.c_int32), ("weighting", C.c_int32), ("n_bin", C.c_int32), ("reserved", C.c_int32),
+                ("lower", C.c_double), ("upper", C.c_double), ("edges", _dp)]
 
 
 class Problem(C.Structure):
@@ -124,6 +130,7 @@ def load(tuning=False):
     lib.mcsas_hip_bgfit.argtypes = [C.c_int32, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]
     lib.mcsas_hip_observability.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, _dp]
     lib.mcsas_hip_histogram_prep.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, _dp, _dp, _dp]
+    lib.mcsas_hip_histogram.argtypes = [C.POINTER(Problem), _dp, C.c_int32, C.POINTER(HistogramSpec), _dp, _dp, _dp]
     lib.mcsas_hip_prepare_uncertainty.argtypes = [C.c_int32, _dp, _dp, C.c_double, C.c_int32, _dp]
     lib.mcsas_hip_rebin.argtypes = [C.c_int32, _dp, _dp, _dp, C.c_int32, _dp, C.c_int32, _dp, _dp, _dp, _i32p]
     lib.mcsas_hip_plugin_compile.argtypes = [C.c_char_p, _i32p]

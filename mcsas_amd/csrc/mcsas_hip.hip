@@ -121,6 +121,146 @@ __global__ __launch_bounds__(64) void hist_obs_kernel(int nq, const double *sigm
     if (threadIdx.x == 0) min_req[(size_t)c * R + r] = best;
 }
 
+
+// ---- McSAS.histogram() on the device (mcsas_hip_histogram) -----------------------------------------------------------------
+// cum[rl][k] = sum_n rows[rl][n][k] in contribution order (scatteringmodel.py:101): one thread per (q, rep), loads in batches of 8
+__global__ void hist_colsum_kernel(int nq, int N, const double *rows, double *cum) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, rl = blockIdx.y;
+    if (k >= nq) return;
+    const double *base = rows + (size_t)rl * N * nq + k;
+    double s = 0.;
+    int n = 0;
+    for (; n + 8 <= N; n += 8) {
+        double v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = base[(size_t)(n + i) * nq];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; n < N; ++n) s += base[(size_t)n * nq];
+    cum[(size_t)rl * nq + k] = s;
+}
+// hist_fit_kernel with the summed intensity given (same sums in the same order): one wave per rep
+__global__ __launch_bounds__(64) void hist_fit_cum_kernel(int nq, const double *I, const double *sigma, int R, int r0, const double *cum,
+                                                          int find_bg, int pos_bg, double *scaling) {
+    const int rl = blockIdx.x, r = r0 + rl, lane = threadIdx.x;
+    double sw = 0, si = 0, sii = 0, sc = 0, scc = 0, sic = 0;
+    for (int k = lane; k < nq; k += WAVE) {
+        const double C = cum[(size_t)rl * nq + k];
+        const double e = sigma[k] == 0.0 ? 1.0 : sigma[k];
+        const double w = 1.0 / (e * e);
+        sw += w; si += w * I[k]; sii += w * I[k] * I[k];
+        sc += w * C; scc += w * C * C; sic += w * I[k] * C;
+    }
+    wave_sum3(sw, si, sii); wave_sum3(sc, scc, sic);
+    ChainArgs a{};
+    a.Sw = sw; a.SI = si; a.SII = sii; a.nq = nq; a.find_bg = find_bg; a.pos_bg = pos_bg;
+    const FitResult f = solve_fit(a, sc, scc, sic);
+    if (lane == 0) { scaling[r] = f.A; scaling[R + r] = f.b; }
+}
+// fractions and their visibility limits, normalised per repetition (mcsas.py:561-604): frac8 = [vf nf qf sf | mv mn mq ms][N][R].
+// One wave per rep; the three totals are taken by one lane each, over the contributions in order (builtin sum()).
+__global__ __launch_bounds__(64) void hist_fractions_kernel(int N, int R, const double *scaling, const double *vset, const double *wset,
+                                                            const double *sset, const double *mv, double *frac8) {
+    __shared__ double tot[3];
+    const int r = blockIdx.x, lane = threadIdx.x;
+    const size_t NR = (size_t)N * R;
+    const double A = scaling[r];
+    double *vf = frac8, *nf = frac8 + NR, *qf = frac8 + 2 * NR, *sf = frac8 + 3 * NR;
+    double *omv = frac8 + 4 * NR, *mn = frac8 + 5 * NR, *mq = frac8 + 6 * NR, *ms = frac8 + 7 * NR;
+    for (int c = lane; c < N; c += WAVE) {
+        const size_t i = (size_t)c * R + r;
+        const double v = vset[i], w = wset[i], s = sset[i], m = mv[i];
+        const double vfc = w * A / v;                          // modeldata.py:57-61
+        const double nfc = vfc / v, mnc = m / v;               // mcsas.py:567-571, :591-594
+        vf[i] = vfc; nf[i] = nfc; qf[i] = vfc * v; sf[i] = nfc * s;
+        omv[i] = m; mn[i] = mnc; mq[i] = mnc * m * m; ms[i] = mnc * s;
+    }
+    __syncthreads();
+    if (lane < 3) {
+        const double *src = lane == 0 ? nf : (lane == 1 ? qf : sf);
+        double t = 0.;
+        for (int c = 0; c < N; ++c) t += src[(size_t)c * R + r];
+        tot[lane] = t;
+    }
+    __syncthreads();
+    const double tn = tot[0], tq = tot[1], ts = tot[2];
+    for (int c = lane; c < N; c += WAVE) {
+        const size_t i = (size_t)c * R + r;
+        if (tn != 0.) { nf[i] /= tn; mn[i] /= tn; }           // :596-604
+        if (tq != 0.) { qf[i] /= tq; mq[i] /= tq; }
+        if (ts != 0.) { sf[i] /= ts; ms[i] /= ts; }
+    }
+}
+struct HistSpecDev { int32_t pidx, weight, nb, pad; int64_t edge_off, out_off; double lo, hi; };
+// One wave per (histogram, repetition).  The repetition's parameter values, fractions and limits are staged in LDS (3 N doubles);
+// lane b owns bin b (64 bins per pass) and walks the contributions in order; the cumulative distribution and the moments are
+// sequential sums again, taken by one lane (two for skew and kurtosis).  utils/parameter.py:84-122, :441-479.
+__global__ __launch_bounds__(64) void hist_bins_kernel(int N, int P, int R, const double *contribs, const double *frac8, const double *edges_all,
+                                                       const HistSpecDev *specs, double *out) {
+    extern __shared__ double hl[];
+    __shared__ double mom[8];
+    const HistSpecDev s = specs[blockIdx.x];
+    const int r = blockIdx.y, lane = threadIdx.x, nb = s.nb;
+    const size_t NR = (size_t)N * R;
+    const double *fr = frac8 + (size_t)s.weight * NR, *lim = frac8 + (size_t)(4 + s.weight) * NR;
+    const double *edges = edges_all + s.edge_off;
+    double *bins = out + s.out_off, *obs = bins + (size_t)nb * R, *cdf = obs + (size_t)nb * R, *mo = cdf + (size_t)nb * R;
+    double *lx = hl, *lf = hl + N, *ll = hl + 2 * (size_t)N;
+    for (int c = lane; c < N; c += WAVE) {
+        lx[c] = contribs[((size_t)c * P + s.pidx) * R + r];
+        lf[c] = fr[(size_t)c * R + r]; ll[c] = lim[(size_t)c * R + r];
+    }
+    __syncthreads();
+    const double last = nb > 0 ? edges[nb] : 0.;
+    for (int b0 = 0; b0 < nb; b0 += WAVE) {
+        const int b = b0 + lane;
+        if (b < nb) {
+            const double elo = edges[b], ehi = edges[b + 1];
+            double sb = 0., so = 0., cnt = 0.;
+            for (int c = 0; c < N; ++c) {
+                const double x = lx[c];
+                if (x >= elo && x < ehi && x < last) { sb += lf[c]; so += ll[c]; cnt += 1.; }
+            }
+            bins[(size_t)b * R + r] = (sb != sb) ? 0. : sb;    // bins[isnan(bins)] = 0
+            obs[(size_t)b * R + r] = cnt > 0. ? so / cnt : 0.;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double run = 0., top = -__builtin_inf();
+        for (int b = 0; b < nb; ++b) { run += bins[(size_t)b * R + r]; cdf[(size_t)b * R + r] = run; top = fmax(top, run); }
+        for (int b = 0; b < nb; ++b) cdf[(size_t)b * R + r] = (top == 0.) ? 0. : cdf[(size_t)b * R + r] / top;
+    }
+    // moments: total, mean, variance by lane 32 (runs beside lane 0's distribution), then skew / kurtosis by lanes 32 / 33
+    if (lane == 32) {
+        double tot = 0., m1 = 0.;
+        int any = 0;
+        for (int c = 0; c < N; ++c) { const double x = lx[c]; const bool ok = x > s.lo && x < s.hi; any |= ok; tot += ok ? lf[c] : 0.; }
+        for (int c = 0; c < N; ++c) { const double x = lx[c]; const bool ok = x > s.lo && x < s.hi; m1 += ok ? x * lf[c] : 0.; }
+        if (tot != 0.) m1 /= tot;
+        double v2 = 0.;
+        for (int c = 0; c < N; ++c) { const double x = lx[c], d = x - m1; const bool ok = x > s.lo && x < s.hi; v2 += ok ? (d * d) * lf[c] : 0.; }
+        const double var = v2 / tot, sg = sqrt(fabs(var));
+        mom[0] = tot; mom[1] = m1; mom[2] = var; mom[3] = sg; mom[4] = (double)any;
+    }
+    __syncthreads();
+    if (lane == 32 || lane == 33) {
+        const double tot = mom[0], m1 = mom[1], sg = mom[3];
+        const bool any = mom[4] != 0., ok3 = any && (tot * sg) != 0. && isfinite(tot * sg);
+        const double sg2 = sg * sg;
+        double acc = 0.;
+        for (int c = 0; c < N; ++c) {
+            const double x = lx[c], d = x - m1, d2 = d * d;
+            const bool ok = x > s.lo && x < s.hi;
+            acc += ok ? (lane == 32 ? d2 * d : d2 * d2) * lf[c] : 0.;
+        }
+        const double val = ok3 ? acc / (tot * (lane == 32 ? sg2 * sg : sg2 * sg2)) : 0.;
+        mo[(size_t)(3 + (lane - 32)) * R + r] = val;
+        if (lane == 32) { mo[r] = any ? tot : 0.; mo[(size_t)R + r] = any ? m1 : 0.; mo[(size_t)2 * R + r] = any ? mom[2] : 0.; }
+    }
+}
+
 // ------------------------------------------------------------------------------ input preparation
 // DataObj._prepareUncertainty (dataobj/dataobj.py:204-227)
 __global__ void prepare_uncertainty_kernel(int n, const double *I, const double *su, double fu_min, double *out) {
@@ -1582,6 +1722,102 @@ extern "C" int mcsas_hip_histogram_prep(const mcsas_problem *p, const double *co
     HIPCHK(hipMemcpy(wset, dw.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(sset, ds.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(min_req_vol, dm.p, sizeof(double) * N * R, hipMemcpyDeviceToHost));
+    return MCSAS_OK;
+}
+
+
+// McSAS.histogram() complete (include/mcsas_hip.h): ONE packed upload (data vectors, parameter sets, bin edges, histogram records) from
+// a pinned staging block, the kernels back to back on the null stream, ONE packed download — a call costs two transfers and no
+// allocation once its block sizes have been seen (MemCache).
+extern "C" int mcsas_hip_histogram(const mcsas_problem *p, const double *contribs, int32_t n_hist, const mcsas_histogram_spec *specs,
+                                   double *scaling, double *fractions, double *out) {
+    if (!p || !contribs || !scaling || !p->q || !p->intensity || !p->sigma || p->nq < 1 || p->n_contrib < 1 || p->n_reps < 1 || n_hist < 0 ||
+        (n_hist > 0 && (!specs || !out)))
+        return fail(MCSAS_EINVAL, "bad argument");
+    if (p->n_contrib > 4096) return fail(MCSAS_EINVAL, "mcsas_hip_histogram stages a repetition's contributions in LDS: n_contrib %d > 4096 (use mcsas_hip_histogram_prep)", p->n_contrib);
+    ModelArgs m;
+    int rc = fill_model_args(p, &m);
+    if (rc) return rc;
+    DeviceGuard dev_guard;
+    rc = select_device(p->device);
+    if (rc) return rc;
+    const size_t Q = p->nq, P = p->n_active, N = p->n_contrib, R = p->n_reps, NR = N * R;
+    size_t n_edges = 0, n_out = 0;
+    std::vector<HistSpecDev> hs((size_t)n_hist);
+    for (int h = 0; h < n_hist; ++h) {
+        const mcsas_histogram_spec &sp = specs[h];
+        if (sp.n_bin < 0 || sp.n_bin > (1 << 20) || sp.param_index < 0 || sp.param_index >= (int)std::max<size_t>(P, 1) || sp.weighting < 0 || sp.weighting > 3 ||
+            (sp.n_bin > 0 && !sp.edges) || P == 0)
+            return fail(MCSAS_EINVAL, "histogram %d: param_index %d, weighting %d, n_bin %d", h, sp.param_index, sp.weighting, sp.n_bin);
+        hs[h] = HistSpecDev{sp.param_index, sp.weighting, sp.n_bin, 0, (int64_t)n_edges, (int64_t)n_out, sp.lower, sp.upper};
+        n_edges += (size_t)sp.n_bin + 1;
+        n_out += (size_t)3 * sp.n_bin * R + 5 * R;
+    }
+    // staging layout (doubles): in = [q | I | sigma | contribs | edges | specs], back = [scaling 2R | fractions 8NR | out]
+    const size_t spec_d = (sizeof(HistSpecDev) * (size_t)n_hist + 7) / 8;
+    const size_t n_in = 3 * Q + N * P * R + n_edges + spec_d, n_back = 2 * R + 8 * NR + n_out;
+    const size_t per_rep = N * Q * sizeof(double);
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(R, ((size_t)8 << 30) / per_rep));
+    DevBuf<double> din, dback, drows, dcum, dvws;
+    HIPCHK(din.alloc(n_in)); HIPCHK(dback.alloc(n_back)); HIPCHK(drows.alloc(chunk * N * Q)); HIPCHK(dcum.alloc(chunk * Q)); HIPCHK(dvws.alloc(4 * NR));
+    struct Pinned {
+        double *p = nullptr; size_t bytes = 0;
+        ~Pinned() { cached_host_free(p, bytes, hipHostMallocDefault); }
+    } hin, hback;
+    hin.bytes = sizeof(double) * n_in; hback.bytes = sizeof(double) * n_back;
+    HIPCHK(cached_host_malloc((void **)&hin.p, hin.bytes, hipHostMallocDefault));
+    HIPCHK(cached_host_malloc((void **)&hback.p, hback.bytes, hipHostMallocDefault));
+    double *w = hin.p;
+    memcpy(w, p->q, sizeof(double) * Q); w += Q;
+    memcpy(w, p->intensity, sizeof(double) * Q); w += Q;
+    memcpy(w, p->sigma, sizeof(double) * Q); w += Q;
+    memcpy(w, contribs, sizeof(double) * N * P * R); w += N * P * R;
+    for (int h = 0; h < n_hist; ++h) { memcpy(w, specs[h].edges, sizeof(double) * ((size_t)specs[h].n_bin + 1)); w += (size_t)specs[h].n_bin + 1; }
+    if (n_hist) memcpy(w, hs.data(), sizeof(HistSpecDev) * (size_t)n_hist);
+    HIPCHK(hipMemcpyAsync(din.p, hin.p, hin.bytes, hipMemcpyHostToDevice, nullptr));
+    const double *dq = din.p, *dI = din.p + Q, *dsg = din.p + 2 * Q, *dc = din.p + 3 * Q, *dedges = dc + N * P * R;
+    const HistSpecDev *dspecs = reinterpret_cast<const HistSpecDev *>(dedges + n_edges);
+    double *dsc = dback.p, *dfrac = dback.p + 2 * R, *dout = dfrac + 8 * NR;
+    double *dv = dvws.p, *dw = dvws.p + NR, *ds = dvws.p + 2 * NR, *dm = dvws.p + 3 * NR;
+    SmearDev smear;
+    rc = smear.upload(p, p->nq, &m);
+    if (rc) return rc;
+    const size_t lds = sizeof(double) * table_doubles_host(p->model_id, m.int_div);
+    for (size_t r0 = 0; r0 < R; r0 += chunk) {
+        const unsigned nr = (unsigned)std::min(chunk, R - r0);
+        const dim3 grid((unsigned)N, nr);
+        switch (p->model_id) {
+#define CASE_K(mm) case mm: hist_rows_kernel<mm><<<grid, WAVE, lds>>>(m, p->nq, dq, (int)N, (int)R, (int)r0, dc, drows.p, dv, dw, ds); break;
+            MCSAS_FOR_MODELS(CASE_K)
+#undef CASE_K
+            default: {
+                if (!is_plugin_model(p->model_id)) return fail(MCSAS_EINVAL, "model %d", p->model_id);
+                int rcp = plugin_small_launch(p->model_id, 2, grid, lds, m, (int)p->nq, (const double *)dq, (int)N, (int)R, (int)r0, (const double *)dc,
+                                              drows.p, dv, dw, ds);
+                if (rcp) return rcp;
+            }
+        }
+        HIPCHK(hipGetLastError());
+        hist_colsum_kernel<<<dim3((unsigned)((Q + 255) / 256), nr), 256>>>(p->nq, (int)N, drows.p, dcum.p);
+        HIPCHK(hipGetLastError());
+        hist_fit_cum_kernel<<<nr, WAVE>>>(p->nq, dI, dsg, (int)R, (int)r0, dcum.p, p->find_background != 0, p->positive_background != 0, dsc);
+        HIPCHK(hipGetLastError());
+        hist_obs_kernel<<<grid, WAVE>>>(p->nq, dsg, (int)N, (int)R, (int)r0, drows.p, dsc, dv, dw, dm);
+        HIPCHK(hipGetLastError());
+    }
+    hist_fractions_kernel<<<(unsigned)R, WAVE>>>((int)N, (int)R, dsc, dv, dw, ds, dm, dfrac);
+    HIPCHK(hipGetLastError());
+    if (n_hist > 0) {
+        if (sizeof(double) * 3 * N > 64 * 1024)
+            HIPCHK(hipFuncSetAttribute((const void *)hist_bins_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 3 * N)));
+        hist_bins_kernel<<<dim3((unsigned)n_hist, (unsigned)R), WAVE, sizeof(double) * 3 * N>>>((int)N, (int)P, (int)R, dc, dfrac, dedges, dspecs, dout);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(hback.p, dback.p, hback.bytes, hipMemcpyDeviceToHost, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    memcpy(scaling, hback.p, sizeof(double) * 2 * R);
+    if (fractions) memcpy(fractions, hback.p + 2 * R, sizeof(double) * 8 * NR);
+    if (n_out) memcpy(out, hback.p + 2 * R + 8 * NR, sizeof(double) * n_out);
     return MCSAS_OK;
 }
 

@@ -356,6 +356,43 @@ def histogram_prep(model: ModelSetup, q, intensity, sigma, contribs, comp_exp, f
     return sc, v, w, s, mv
 
 
+HISTOGRAM_MAX_CONTRIBS = 4096     # mcsas_hip_histogram stages a repetition's contributions in LDS
+YWEIGHT_INDEX = {"vol": 0, "num": 1, "int": 2, "surf": 3}
+
+
+def histogram_device(model: ModelSetup, q, intensity, sigma, contribs, comp_exp, specs, find_background=True,
+                     positive_background=False, device=-1, smear=None):
+    """McSAS.histogram() (mcsas.py:445-615) for all repetitions on the device in one call (mcsas_hip_histogram).
+    `specs`: per histogram a dict(param_index, yweight, edges (n_bin + 1 lower edges), lower, upper).
+    Returns (scaling[2][R], fractions dict like mcsas.histogram's {'vol': (vf, mv), ...}, per histogram a dict with
+    bins[n_bin][R], obs[n_bin][R], cdf[n_bin][R], moments[5][R])."""
+    lib = _lib.load()
+    contribs = f64(contribs)
+    N, P, R = contribs.shape
+    st = Settings(n_contrib=N, n_reps=R, comp_exp=comp_exp, device=device, find_background=find_background,
+                  positive_background=positive_background)
+    prob = HipProblem(model, q, intensity, sigma, st, smear=smear)
+    arr = (_lib.HistogramSpec * max(len(specs), 1))()
+    keep, n_out = [], 0
+    for h, sp in enumerate(specs):
+        e = f64(sp["edges"]).ravel()
+        keep.append(e)
+        arr[h].param_index = int(sp["param_index"]); arr[h].weighting = YWEIGHT_INDEX[sp["yweight"]]
+        arr[h].n_bin = len(e) - 1; arr[h].lower = float(sp["lower"]); arr[h].upper = float(sp["upper"]); arr[h].edges = as_dp(e)
+        n_out += 3 * (len(e) - 1) * R + 5 * R
+    sc = np.zeros((2, R)); frac = np.zeros((8, N, R)); out = np.zeros(max(n_out, 1))
+    check(lib.mcsas_hip_histogram(C.byref(prob.c), as_dp(contribs), len(specs), arr, as_dp(sc), as_dp(frac), as_dp(out)), lib)
+    fractions = dict(vol=(frac[0], frac[4]), num=(frac[1], frac[5]), int=(frac[2], frac[6]), surf=(frac[3], frac[7]))
+    hists, off = [], 0
+    for sp, e in zip(specs, keep):
+        nb = len(e) - 1
+        blk = out[off:off + 3 * nb * R + 5 * R]
+        hists.append(dict(bins=blk[:nb * R].reshape(nb, R), obs=blk[nb * R:2 * nb * R].reshape(nb, R),
+                          cdf=blk[2 * nb * R:3 * nb * R].reshape(nb, R), moments=blk[3 * nb * R:].reshape(5, R)))
+        off += 3 * nb * R + 5 * R
+    return sc, fractions, hists
+
+
 def prepare_uncertainty(intensity, sigma_raw, fu_min, device=-1):
     """DataObj._prepareUncertainty (dataobj/dataobj.py:204-227) on the GPU."""
     lib = _lib.load()

@@ -174,9 +174,23 @@ class McSAS(object):
         setup = setup_from_model(model, data)
         smear = data.smearArgs(model) if hasattr(data, "smearArgs") else None
         c = self.compensationExponent()
+        sig = np.array(data.f.binnedDataU, dtype=float)
+        # Everything on the device in one call (mcsas_hip_histogram): model.calc, the scale / background fit, the visibility
+        # limits, the fractions, and per configured histogram the bins, CDF and moments of every repetition — their mean / std over
+        # the repetitions is taken here.  (More than engine.HISTOGRAM_MAX_CONTRIBS contributions: the two-step path below.)
+        if numContribs <= engine.HISTOGRAM_MAX_CONTRIBS:
+            todo = [(pi, h) for pi, param in enumerate(model.activeParams()) for h in param.histograms()]
+            specs = [h.deviceSpec(pi) for pi, h in todo]
+            scalingFactors, fractions, res = engine.histogram_device(
+                setup, data.q, data.f.binnedData, sig, contribs, c, specs, self.findBackground.value(),
+                self.positiveBackground.value(), device=self.device, smear=smear)
+            self.result[0]['scalingFactors'] = scalingFactors
+            self.fractions = fractions
+            for (pi, h), r in zip(todo, res):
+                h.setFromDevice(r)
+            return
         # model.calc, the scale/background fit and the N single-row visibility limits of every repetition
         # (:552, :559, :575-590): one library call for all of them
-        sig = np.array(data.f.binnedDataU, dtype=float)
         scalingFactors, vsets, wsets, ssets, mv = engine.histogram_prep(
             setup, data.q, data.f.binnedData, sig, contribs, c, self.findBackground.value(),
             self.positiveBackground.value(), device=self.device, smear=smear)

@@ -259,6 +259,16 @@ class Moments(object):
         self.variance = (var.mean(), var.std(ddof=ddof)); self.skew = (skw.mean(), skw.std(ddof=ddof))
         self.kurtosis = (krt.mean(), krt.std(ddof=ddof))
 
+    @classmethod
+    def fromRepetitions(cls, val, mu, var, skw, krt):
+        """The per-repetition moments worked out elsewhere (mcsas_hip_histogram) -> their mean / std over the repetitions."""
+        self = cls.__new__(cls)
+        ddof = 1 if len(val) > 1 else 0
+        self.total = (val.mean(), val.std(ddof=ddof)); self.mean = (mu.mean(), mu.std(ddof=ddof))
+        self.variance = (var.mean(), var.std(ddof=ddof)); self.skew = (skw.mean(), skw.std(ddof=ddof))
+        self.kurtosis = (krt.mean(), krt.std(ddof=ddof))
+        return self
+
     @property
     def fields(self):
         return self.total + self.mean + self.variance + self.skew + self.kurtosis
@@ -358,9 +368,23 @@ class Histogram(object):
         top = cdf.max(axis=0) if nb else np.zeros(numReps)
         with np.errstate(invalid='ignore', divide='ignore'):
             cdf = np.where(top[None, :] == 0.0, 0., cdf / top[None, :])
+        self._setResults(bins, allObs, cdf)
+        self.moments = Moments(contribs, paramIndex, self.xrange, frac)
+
+    def _setResults(self, bins, allObs, cdf):
+        nb, numReps = bins.shape
         self.bins = VectorResult(bins)
         self.cdf = VectorResult(cdf)
         finite = np.where(allObs < np.inf, allObs, -np.inf)   # _setObservability :390-402
         best = finite.max(axis=1) if numReps else np.zeros(nb)
         self.observability = np.where(np.isfinite(best), best, 0.)
-        self.moments = Moments(contribs, paramIndex, self.xrange, frac)
+
+    def deviceSpec(self, paramIndex):
+        """What mcsas_hip_histogram needs to know about this histogram (engine.histogram_device)."""
+        self._setXLowerEdge()
+        return dict(param_index=paramIndex, yweight=self.yweight, edges=self.xLowerEdge, lower=min(self.xrange), upper=max(self.xrange))
+
+    def setFromDevice(self, res):
+        """bins / obs / cdf / moments of every repetition as mcsas_hip_histogram returns them (engine.histogram_device)."""
+        self._setResults(np.array(res["bins"]), np.array(res["obs"]), np.array(res["cdf"]))
+        self.moments = Moments.fromRepetitions(*[np.array(x) for x in res["moments"]])

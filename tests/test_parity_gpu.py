@@ -947,6 +947,56 @@ def test_histogram_prep_equals_the_per_call_entry_points():
     np.testing.assert_allclose(mv, frac["vol"][1], rtol=1e-7)
 
 
+@pytest.mark.parametrize("tag", ["sphere", "cyl_aspect", "ellcs"])
+def test_device_histogram_equals_the_two_step_host_path(tag):
+    """mcsas_hip_histogram (fractions, bins, CDF, observability, moments of every repetition on the device, ordered sums) against
+    mcsas_hip_histogram_prep + the numpy half of McSAS.histogram(): the same numbers, bit for bit, for every weighting, linear and
+    logarithmic bins, more than 64 bins, bins nobody falls into, a range narrower than the parameter's."""
+    q, I, sig = _synthetic(100)
+    lo, hi = RANDOM_RANGES[tag]
+    m, _ = make_models(tag, lo, hi, **({"intDiv": 20.} if tag != "sphere" else {}))
+    ap = m.activeParams()
+    decl = [(0, 50, 'log', 'vol', 1.0), (0, 130, 'lin', 'num', 1.0), (len(ap) - 1, 7, 'log', 'int', 0.5), (len(ap) - 1, 12, 'lin', 'surf', 1.0)]
+    for pi, nb, xs, yw, shrink in decl:
+        p = ap[pi]
+        a, b = p.activeRange()
+        p.histograms().append(mcsas_amd.Histogram(p, a, a + shrink * (b - a), binCount=nb, xscale=xs, yweight=yw, autoFollow=False))
+    algo = mcsas_amd.McSAS(seed=3)
+    algo.numContribs.setValue(90); algo.numReps.setValue(7); algo.maxIterations.setValue(600); algo.convergenceCriterion.setValue(1e-9)
+    algo.showIncomplete.setValue(True); algo.model = m
+    algo.data = mcsas_amd.SASData(q, I, sig)
+    algo.result = []; algo.stop = False
+    algo.analyse()
+
+    def snapshot():
+        out = []
+        for p in ap:
+            for h in p.histograms():
+                out.append(dict(bins=np.array(h.bins.full), bm=np.array(h.bins.mean), bs=np.array(h.bins.std), cdf=np.array(h.cdf.full),
+                                obs=np.array(h.observability), mom=np.array(h.moments.fields, dtype=float), edges=np.array(h.xLowerEdge)))
+        fr = {k: (np.array(v[0]), np.array(v[1])) for k, v in algo.fractions.items()}
+        return out, fr, np.array(algo.result[0]['scalingFactors'])
+
+    algo.histogram()
+    dev, dfr, dsc = snapshot()
+    cap = engine.HISTOGRAM_MAX_CONTRIBS
+    engine.HISTOGRAM_MAX_CONTRIBS = 0                          # force the two-step path
+    try:
+        algo.histogram()
+    finally:
+        engine.HISTOGRAM_MAX_CONTRIBS = cap
+    host, hfr, hsc = snapshot()
+    np.testing.assert_array_equal(dsc, hsc)
+    for k in hfr:
+        np.testing.assert_array_equal(dfr[k][0], hfr[k][0], err_msg=k)
+        np.testing.assert_array_equal(dfr[k][1], hfr[k][1], err_msg=k)
+    assert len(dev) == 4
+    for d, h in zip(dev, host):
+        for k in d:
+            np.testing.assert_array_equal(d[k], h[k], err_msg=k)
+    assert sum(d["bins"].sum() > 0 for d in dev) >= 3          # (the surface weighting of a model without surface() is all zero)
+
+
 def test_uncertainty_floor_special_values():
     """_prepareUncertainty's corner cases (dataobj/dataobj.py:204-227): the floor wins over smaller and over
     zero uncertainties, non-finite results become +inf, negative intensities give a negative floor that the
