@@ -1203,28 +1203,25 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
             const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
             const auto nrow = cache + (size_t)sslot * qpad + lane;
             const auto dr = dwin + (size_t)k * qpad + lane;
-            double d[QPL], nwv[QPL], ocur[QPL];
-            RowEval<M, QPL>::run(cnew, qt, lane, nwv);
-            PIPE_PIN_ROW(nwv);
-            {
-                const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bl) * qpad + lane;
-#pragma unroll
-                for (int j = 0; j < QPL; ++j) ocur[j] = orow[WAVE * j];
-            }
-            PIPE_PIN_ROW(ocur);                                   // the `old` row has landed before the first store is issued
             // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  (Taking the
             // sums in the scan block's pass over the row instead was measured: its single h pass is the serial part of a
             // tick, 5x the dot-product work there cost 8 us per tick, here it is spread over every CU.)
+            // Every q slot is consumed the moment the evaluator has it (RowEval::run_each) and nothing of the row stays in registers
+            // across the evaluation of the next slot (the row arrays used to be spilled to scratch around every slot: 20-30 KB per
+            // step).  The `old` value of a slot is requested one slot ahead: it lands while that slot is evaluated.
+            const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bl) * qpad + lane;
             double s1 = 0., s2 = 0., s3 = 0.;
-#pragma unroll
-            for (int j = 0; j < QPL; ++j) {
+            double o_ahead = orow[0];
+            RowEval<M, QPL>::run_each(cnew, qt, lane, [&](int j, double v) {
                 const int iq = lane + WAVE * j;
-                nrow[WAVE * j] = nwv[j];
-                d[j] = nwv[j] - ocur[j];
-                dr[WAVE * j] = d[j];
-                const double wd = lw[iq] * d[j];
-                s1 += wd; s2 = fma(lwI[iq], d[j], s2); s3 = fma(wd, d[j], s3);
-            }
+                const double o = o_ahead;
+                o_ahead = orow[WAVE * (j + 1 < QPL ? j + 1 : j)];
+                nrow[WAVE * j] = v;
+                const double dj = v - o;
+                dr[WAVE * j] = dj;
+                const double wd = lw[iq] * dj;
+                s1 += wd; s2 = fma(lwI[iq], dj, s2); s3 = fma(wd, dj, s3);
+            });
             wave_sum3(s1, s2, s3);
             if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
 #pragma unroll

@@ -194,9 +194,18 @@ template <> struct Contrib<MCSAS_MODEL_CYL_ISO> {
     // same order as before: same bits.
     template <int QPL>
     __device__ __forceinline__ void rows_rt(const QTables &t, int lane, double (&out)[QPL]) const {
-        double q[QPL], invq[QPL], acc[QPL];
 #pragma unroll
-        for (int j = 0; j < QPL; ++j) { q[j] = 0.; invq[j] = 0.; acc[j] = 0.; }
+        for (int j = 0; j < QPL; ++j) out[j] = 0.;
+        rows_rt_each<QPL>(t, lane, [&](int js, double o) {
+#pragma unroll
+            for (int j = 0; j < QPL; ++j) out[j] = (j == js) ? o : out[j];
+        });
+    }
+    // the same, each q slot handed to `sink(slot, value)` as soon as it is finished — end columns, trapezoid, weight inside the
+    // slot's own iteration — so that NO per-slot array lives across the slot loop (q, 1/q and the sums of all slots used to: spilled
+    // and reloaded once per slot; a caller that stores the value at once keeps the evaluation's registers to the evaluation)
+    template <int QPL, class Sink>
+    __device__ __forceinline__ void rows_rt_each(const QTables &t, int lane, Sink &&sink) const {
         const double *rt = t.rowtab;
         constexpr int G = 7;                                  // (K = 100: 98 interior orientations = 14 groups; groups of 4: 2 % slower)
 #pragma nounroll
@@ -237,19 +246,14 @@ template <> struct Contrib<MCSAS_MODEL_CYL_ISO> {
                 const double gg = (j1_core(qj * A, iqj * iA) * s1) * C;
                 a = fma(gg, gg, a);
             }
-#pragma unroll
-            for (int j = 0; j < QPL; ++j) if (j == js) { q[j] = qj; invq[j] = iqj; acc[j] = a; }
-        }
-#pragma unroll
-        for (int j = 0; j < QPL; ++j) {
-            const double qr = q[j] * r, qh = q[j] * hl;
+            const double qr = qj * r, qh = qj * hl;
             const double f0 = 0.5 * (j1_fast(qr) / qr);          // end columns: analytic limits (:79-82)
             double sq, cq;
             sincos_core(qh, &sq, &cq);
             const double fl = sq / qh;
-            const double iq2 = invq[j] * invq[j];
-            const double trapz = (0.5 * step) * (f0 * f0 + fl * fl + 2. * (acc[j] * (iq2 * iq2)));
-            out[j] = (16. * trapz) * w;
+            const double iq2 = iqj * iqj;
+            const double trapz = (0.5 * step) * (f0 * f0 + fl * fl + 2. * (a * (iq2 * iq2)));
+            sink(js, (16. * trapz) * w);
         }
     }
     __device__ __forceinline__ double intensity(double q, const double *tab) const {
@@ -794,6 +798,35 @@ __device__ __forceinline__ double row_cost(const Contrib<M> &c, const double *lq
 // are worked out once per row into the wave's LDS scratch, which leaves two multiplies, the branch-free
 // sincos (and J1) and two FMAs per (q, k).
 template <int M, int QPL> struct RowEval {
+    // The row one q slot at a time, slot j's value handed to sink(j, value) in slot order as soon as it is known.  Rows that cost an
+    // integral per point are evaluated slot by slot anyway, and a caller that consumes the value at once (the pipeline's
+    // producer: d = new - old, its stores and sums) leaves no row array alive across the evaluation.
+    template <class Sink>
+    static __device__ __forceinline__ void run_each(const Contrib<M> &c, const QTables &t, int lane, Sink &&sink) {
+        if constexpr (Contrib<M>::ROW_CLASS != 0 && !Contrib<M>::CAN_SMEAR) {
+            if constexpr (M == MCSAS_MODEL_CYL_ISO) {
+                if (t.rowtab && c.fast) {
+                    c.fill_rowtab(t.tab, t.rowtab, lane);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    c.template rows_rt_each<QPL>(t, lane, sink);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    return;
+                }
+            }
+            if constexpr (Contrib<M>::ROWTAB == 0) {
+#pragma nounroll
+                for (int js = 0; js < QPL; ++js) sink(js, c.intensity(t.q[lane + WAVE * js], t.tab));
+                return;
+            }
+        }
+        double out[QPL];
+        run(c, t, lane, out);
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) sink(j, out[j]);
+    }
     static __device__ __forceinline__ void run(const Contrib<M> &c, const QTables &t, int lane, double (&out)[QPL]) {
         if constexpr (Contrib<M>::CAN_SMEAR) {
             if (t.smear_nk > 0) {
@@ -815,8 +848,21 @@ template <int M, int QPL> struct RowEval {
                 return;
             }
         }
+        if constexpr (Contrib<M>::ROW_CLASS != 0) {
+            // a point of these models is an integral (hundreds to thousands of instructions, loops and branches of its own):
+            // ONE copy of it, run once per q slot — QPL inlined copies multiply the code and the values live at their joins
 #pragma unroll
-        for (int j = 0; j < QPL; ++j) out[j] = c.intensity(t.q[lane + WAVE * j], t.tab);
+            for (int j = 0; j < QPL; ++j) out[j] = 0.;
+#pragma nounroll
+            for (int js = 0; js < QPL; ++js) {
+                const double o = c.intensity(t.q[lane + WAVE * js], t.tab);
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) out[j] = (j == js) ? o : out[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < QPL; ++j) out[j] = c.intensity(t.q[lane + WAVE * j], t.tab);
+        }
     }
 };
 
@@ -831,6 +877,13 @@ __device__ __forceinline__ QTables make_qtables(const ModelArgs &a, const double
     return QTables{q, q3inv, tab, rt, a.smear_locs_t, a.smear_cw, Contrib<M>::CAN_SMEAR ? a.smear_nk : 0, a.smear_stride};
 }
 template <int QPL> struct RowEval<MCSAS_MODEL_SPHERE, QPL> {
+    template <class Sink>                                      // (see the general template; a sphere's row is evaluated whole)
+    static __device__ __forceinline__ void run_each(const Contrib<MCSAS_MODEL_SPHERE> &c, const QTables &t, int lane, Sink &&sink) {
+        double out[QPL];
+        run(c, t, lane, out);
+#pragma unroll
+        for (int j = 0; j < QPL; ++j) sink(j, out[j]);
+    }
     static __device__ __forceinline__ void run(const Contrib<MCSAS_MODEL_SPHERE> &c, const QTables &t, int lane,
                                                double (&out)[QPL]) {
         if (t.smear_nk > 0) {
