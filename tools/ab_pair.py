@@ -17,7 +17,7 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 K = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 q, I, sig = synthetic_data(512)
 m = mcsas_amd.Sphere(); m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
-st = engine.Settings(n_contrib=400, n_reps=50, max_iter=20000, conv_crit=0.0, max_retries=0, seed=20250101)
+st = engine.Settings(n_contrib=400, n_reps=50, max_iter=int(os.environ.get("AB_STEPS", "20000")), conv_crit=0.0, max_retries=0, seed=20250101)
 plans = []
 for k in range(K):
     for which, p in enumerate(paths):
