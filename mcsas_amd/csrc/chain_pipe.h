@@ -982,6 +982,9 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                     const auto dr = dwin + (size_t)k * qpad + lane;
                     double *dl = dbuf + (size_t)(rbase + jr) * dstr + lane;
                     RowEval<M, QPL>::run(cnew, qt, lane, nwv);
+#ifdef MCSAS_STAMPS                                               /* marks 4..11: my first four rows — evaluated / `old` rows there and stores out */
+                    if (l < 4) { PIPE_PIN_ROW(nwv); PIPE_TL_MARK(pa, t, 4 + 2 * l); }
+#endif
                     PIPE_PIN_ROW(ocur); PIPE_PIN_ROW(onext); PIPE_PIN_ROW(nwv);   // both `old` rows have landed before the first store is issued
                     double s1 = 0., s2 = 0.;
 #pragma unroll
@@ -998,6 +1001,9 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
                     if (lane < 2) scal[(size_t)k * 4 + lane] = ae;
 #pragma unroll
                     for (int j = 0; j < QPL; ++j) ocur[j] = onext[j];
+#ifdef MCSAS_STAMPS
+                    if (l < 4) PIPE_TL_MARK(pa, t, 5 + 2 * l);
+#endif
                 }
                 PIPE_TL_MARK(pa, t, 2 * (ss < 4 ? ss : 3));
                 if (!no_gram) PIPE_LDS_BARRIER();                 // the sub-window's rows are in LDS

@@ -60,7 +60,7 @@ def main():
     md = ["# Profiles %s (MI355X, rocprofv3; raw passes by tools/profile.sh, this file by tools/pmc_summary.py)" % ROUND, "",
           "Counter passes run with `--kernel-trace --pmc ...` only, the bench program directly after `--`; every pass is its own run.",
           "SQ_* counters are sums over all shader engines of the dispatches of the named kernel; *_CYCLES in quad-cycles.",
-          "Kernel durations under `--kernel-trace` run ~6 % above the un-profiled ones (config 2: 107 ticks x the average below = the launch time "
+          "Kernel durations under `--kernel-trace` run ~6 %% above the un-profiled ones (config 2: 107 ticks x the average below = the launch time "
           "the bench reports UNDER the same pass; profiles/%s_bench_line.json is bench.py without a profiler)." % ROUND, ""]
     valu = {}
     works = [("c2", 2, r"pipe_tick_kernel"), ("c3", 3, r"pipe_tick_kernel"), ("c4", 4, r"pipe_tick_kernel"), ("c5", 5, r"pipe_tick_kernel"),
