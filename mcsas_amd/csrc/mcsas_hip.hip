@@ -1004,13 +1004,15 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
                 // repetitions).  A device with another CU count is asked at the repetition count that loads it the same.
                 mode = auto_mode_light(qpad, p->n_contrib, (double)p->n_reps * 256.0 / (double)n_cus, pipe_ok, wg_ok);
             } else {
-                // rows that cost an integral each keep the workgroup's seven producer waves per chain until the chains alone
-                // fill the SIMDs (round 2, tools/mode_sweep_heavy.py: cylinders 5.1-5.4e6 steps/s in the pipeline at any chain
-                // count, 3.7 / 5.1 / 5.0e6 per workgroup at 192 / 256 / 512 chains; Kholodenko 3.3-3.5e6 in the pipeline,
-                // 3.2 / 4.3 / 4.3e6 per workgroup, 4.0 / 5.2e6 per wavefront at 1024 / 2048); thresholds in units of a 256-CU device
+                // Rows that cost an integral each: the pipeline at every chain count up to where the chains alone fill the SIMDs twice
+                // over (round 4, tools/sweep_heavy_modes2.sh, 6000-10 000 steps per chain: cylinders 5.5 / 5.6 / 5.5e6 steps/s in the
+                // pipeline at 256 / 512 / 1024 chains against 4.8 / 4.8 / 4.7e6 per workgroup and 1.3 / 2.5 / 4.9e6 per wavefront;
+                // Kholodenko 4.6 / 4.6 / 4.5 / 4.5e6 at 256 ... 2048 against 4.0 / 4.0 / 3.9 / 3.8e6 and 1.0 / 1.9 / 3.8 / 4.8e6;
+                // core-shell ellipsoids at 400 chains 3.7e6 against 1.5e6 per wavefront — round 2's thresholds (pipeline up to 192
+                // chains, workgroup up to 1024) predate the cost-balanced deal of the rows).  Units of a 256-CU device.
                 const double r_eff = (double)p->n_reps * 256.0 / (double)n_cus;
-                if (r_eff >= 1024.) mode = MCSAS_EXEC_WAVE;
-                else if (r_eff <= 192. && pipe_ok) mode = MCSAS_EXEC_PIPELINE;
+                if (r_eff < 1536. && pipe_ok) mode = MCSAS_EXEC_PIPELINE;
+                else if (r_eff >= 1024.) mode = MCSAS_EXEC_WAVE;
                 else if (wg_ok) mode = MCSAS_EXEC_WORKGROUP;
                 else mode = MCSAS_EXEC_WAVE;
             }

@@ -997,6 +997,21 @@ def test_device_histogram_equals_the_two_step_host_path(tag):
     assert sum(d["bins"].sum() > 0 for d in dev) >= 3          # (the surface weighting of a model without surface() is all zero)
 
 
+def test_auto_mode_for_rows_with_an_integral():
+    """MCSAS_EXEC_AUTO for models whose rows cost an integral (round 4 sweep, tools/sweep_heavy_modes2.sh): the pipeline up to where the
+    chains alone fill the SIMDs twice over — BASELINE's totals of configs 3 and 4 on one GPU (200 / 400 chains) included —, one
+    wavefront per chain beyond."""
+    q, I, sig = _synthetic(128)
+    m, _ = make_models("cyl_aspect", *RANDOM_RANGES["cyl_aspect"], intDiv=20.)
+    for reps, want in ((13, "pipeline"), (200, "pipeline"), (400, "pipeline"), (1024, "pipeline"), (2048, "wave")):
+        st = engine.Settings(n_contrib=64, n_reps=reps, max_iter=50, conv_crit=0.0, max_retries=0, seed=1)
+        plan = engine.Plan(m.setup(), q, I, sig, st)
+        if engine.device_count() and plan.info["exec_mode"] != want:
+            import torch
+            assert torch.cuda.get_device_properties(0).multi_processor_count != 256, (reps, plan.info)   # (thresholds scale with the CU count)
+        plan.close()
+
+
 def test_uncertainty_floor_special_values():
     """_prepareUncertainty's corner cases (dataobj/dataobj.py:204-227): the floor wins over smaller and over
     zero uncertainties, non-finite results become +inf, negative intensities give a negative floor that the
