@@ -101,6 +101,9 @@ struct PipeGeom {
     int32_t resum_every;          // 0: the running sums are re-derived from ft at the end of every window (the window is fixed: rows without an
                                   // integral); n: at every n-th step of the attempt instead, and chi²·Q is carried across windows exactly —
                                   // nothing a chain decides then depends on the window, which follows the chain count for rows with an integral
+    int32_t rowq;                 // rows with an integral (round 4): the producer waves of a chain PULL the window's rows from a queue, most expensive
+                                  // first (no static deal), and the scan block works out the 8-step Gram blocks itself from the rows in its LDS
+    int32_t rec_off;              // rowq: producer LDS offset (doubles) of the window's proposal records
     uint64_t prod_lds, scan_lds;
 };
 
@@ -117,6 +120,7 @@ struct PipeArgs {
     int32_t *row_valid;           // [R][N]  lazy_rows: 1 = the contribution's cached row is current
     double *pval;                 // [R][2][kb][MAX_ACTIVE]
     int32_t *povf;                // [R][2][kb]
+    int32_t *rowq;                // [R][2]  rowq: next row of the window to hand out, by tick parity (zeroed by the scan block a tick ahead)
     int32_t *n_done;              // host-mapped: set to the number of chains when the last one has finished
     int32_t *n_done_dev;          // device counter behind it (one system-scope atomic per chain cost the last tick 30 us)
     int32_t tick, pad;            // unused: the tick travels as its own kernel argument
@@ -156,27 +160,48 @@ constexpr int PIPE_RESUM_STEPS = 64;        // rows with an integral: the runnin
 constexpr int PIPE_MAX_ROW_DOUBLES = 32;   // scan block: doubles per lane held in row registers (rows per wave and sub-window x q per lane)   // 16x16 tiles reduced across the 8 waves per LDS round (32 KB)
 
 // rows_per_wave_req: 0 = automatic, else the requested rows per producer wave (diagnostic / tuning)
-static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int sub_req, int gram_global_req, int eager_req, int n_chains, int n_cus, PipeGeom *g) {
+static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heavy_rows, int rows_per_wave_req, int sub_req, int gram_global_req, int eager_req, int n_chains, int n_cus, PipeGeom *g,
+                                int contrib_doubles) {
     int qpl = 1;
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
     const int qpad = qpl * 64;
+    g->rowq = 0; g->rec_off = 0;
+    if (heavy_rows) {
+        // Rows that cost an integral each (round 4).  The window is as long as 2 Kb <= N allows (a multiple of the 8-step Gram
+        // blocks, at most 256 steps: one proposal per thread of the first half of a block) — it no longer follows the chain count
+        // —, every chain gets the producer blocks that are left beside the scan blocks, and their waves pull the window's rows from
+        // a queue in order of predicted cost: a wave that drew a cheap row simply comes back sooner.
+        int kb = (n_contrib / 2) & ~7;
+        if (kb > 256) kb = 256;
+        if (kb < 8) return 1;
+        // producer blocks per chain: enough to cover every CU by themselves — the launch then holds more workgroups than CUs, the
+        // scan blocks (dispatched first) are done within a tenth of a tick, and the producer blocks that were waiting take over
+        // their CUs and pull what is left of their chain's window (a static deal would leave those CUs idle for the rest of the tick)
+        int by = 8;
+        if (n_chains > 0 && n_cus > 0) { by = (n_cus + n_chains - 1) / n_chains; if (by < 1) by = 1; if (by > 32) by = 32; if (by * 8 > kb) by = (kb + 7) / 8; }
+        g->kb = kb; g->qpl = qpl; g->w = 8; g->sub_per_block = 1; g->rows_per_wave = 1; g->prod_blocks_y = by;
+        g->gram_off = 4 * qpad + tab_doubles; g->resum_every = PIPE_RESUM_STEPS;
+        g->overlap = 0; g->gram_lds = 0; g->drow_off = 0; g->lazy_rows = 0;
+        g->rowq = 1; g->rec_off = g->gram_off + 16;
+        const size_t rec = (size_t)kb * (contrib_doubles + MCSAS_MAX_ACTIVE + 2) + ((size_t)3 * kb + 1) / 2;      // records; rank -> step and the two row slots (int32)
+        g->prod_lds = sizeof(double) * ((size_t)g->rec_off + rec);
+        g->scan_waves = PIPE_WAVES;
+        g->scan_lds = sizeof(double) * ((size_t)g->w * qpad + 2 * (size_t)g->w * g->w + 2 * (size_t)qpad + (size_t)g->kb * 4 + 64)
+                    + sizeof(int32_t) * (4 * (size_t)g->kb + 1 + 1 + 64 + 4 + 8) + 64;
+        if (g->scan_lds > 160 * 1024 || g->prod_lds > 160 * 1024) return 1;
+        return 0;
+    }
     // window: as many steps as 2*Kb <= N allows, Kb = (sub-windows) x (8 producer waves) x (rows per wave).
     // Rows per wave set the sub-window W = 8 rpw: measured on config 2 (tools/sweep_flags.sh) W = 48 beats 64
     // (Gram tiles per step fall from 10/64 to 6/48 and four producer blocks per chain instead of three fill
     // the CUs the scan blocks leave free) and 32 (more scan sub-windows per tick): candidates in that order,
     // the first one whose window is within 15 % of the largest wins.
-    // Rows that cost a numerical integration each (cylinders, ellipsoids, worm-like chains): one row per
-    // producer wave, so that a window is R*Kb waves for the 1024 SIMDs instead of R*Kb/8.
     // scan sub-window for `r` rows per producer wave: the largest multiple of 8 that divides the producer block's rows and
     // whose d rows fit the scan block's LDS row buffer (the accepted rows are applied to ft from there, not from HBM).
-    // Rows without an integral run the overlapped producer (Gram of sub-window s between the rows of s + 1), whose tile
-    // schemes cover W <= 32.
-    const bool overlap = !heavy_rows && gram_global_req;
+    // The overlapped producer (Gram of sub-window s between the rows of s + 1) has tile schemes for W <= 32.
+    const bool overlap = gram_global_req;
     auto pick_w = [&](int r) {
-        // rows with an integral: always 8 — which steps share a Gram block must not follow the rows per wave, and those
-        // follow the chain count (a repetition's result is to be the same beside 6 other chains as beside 49)
-        if (heavy_rows) return 8;
         int w = 8;
         for (int ws = 8; ws <= 8 * r && ws <= (overlap ? 32 : 64); ws += 8) {
             const int rps = ws / 8;
@@ -186,35 +211,12 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         return w;
     };
     int rpw = 0, by = 0;
-    if (rows_per_wave_req >= 1 && rows_per_wave_req <= 8) rpw = rows_per_wave_req;
-    else if (heavy_rows) rpw = 1;
-    if (rpw) {
+    if (rows_per_wave_req >= 1 && rows_per_wave_req <= 8) {
+        rpw = rows_per_wave_req;
         while (rpw > 1 && 2 * 8 * rpw > n_contrib) --rpw;
         if (2 * 8 * rpw > n_contrib) return 1;
         by = n_contrib / (2 * 8 * rpw);
         if (by * 8 * rpw > 256) by = 256 / (8 * rpw);
-        // Rows with an integral: a block's time is its waves' rows whatever the window, and the launch takes
-        // ceil(blocks / CUs) such rounds — the rows per wave and the producer blocks per chain that give the most steps per
-        // unit of time win (13 Kholodenko chains: 18 blocks per chain = 247 blocks in ONE round, instead of 32 = 429 blocks
-        // in two).  heavy_rows == 2: the cost of a row varies with its parameters (worm-like chains: up to 5x with the Kuhn
-        // length; cylinders: with the Bessel function's branch).  With one row per wave a round lasts as long as the chip's
-        // most expensive row (factor ~1.5 over the mean); two rows per wave, dealt by predicted cost (pipe_prod_block), bring a
-        // wave's total within ~10 % of the mean and double the window a round covers.
-        if (heavy_rows && rows_per_wave_req == 0 && n_chains > 0 && n_cus > 0) {
-            static const double spread[5] = {0., 1.5, 1.12, 1.08, 1.06};       // a round's duration / (rows per wave x mean row), varying costs
-            int best_r = 1, best_b = by; double best_rate = 0.;
-            for (int r = 1; r <= (heavy_rows == 2 ? 4 : 1); ++r) {
-                if (2 * 8 * r > n_contrib) break;
-                int bmax = n_contrib / (2 * 8 * r);
-                if (bmax * 8 * r > 256) bmax = 256 / (8 * r);
-                for (int b = 1; b <= bmax; ++b) {
-                    const int rounds = (n_chains * (b + 1) + n_cus - 1) / n_cus;
-                    const double rate = (double)(b * 8 * r) / (rounds * r * (heavy_rows == 2 ? spread[r] : 1.0));
-                    if (rate > best_rate * (1.0 + 1e-9) || (rate >= best_rate * (1.0 - 1e-9) && r == best_r && b > best_b)) { best_rate = rate; best_r = r; best_b = b; }
-                }
-            }
-            rpw = best_r; by = best_b;
-        }
     } else {
         static const int order[6] = {6, 8, 4, 3, 2, 1};
         int kbs[6], best_kb = 0;
@@ -254,7 +256,7 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     g->rows_per_wave = rpw;
     g->prod_blocks_y = by;
     g->gram_off = 4 * qpad + tab_doubles;
-    g->resum_every = heavy_rows ? PIPE_RESUM_STEPS : 0;
+    g->resum_every = 0;
     {
         // reduction buffer of the Gram tiles: [8 waves][tiles][256]; the overlapped producer keeps two of them (the block of
         // sub-window s is summed while the partial tiles of s + 1 are being parked)
@@ -265,7 +267,7 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         // in LDS on their way to HBM it is MFMA-bound instead of waiting for an L2 round trip per sub-window.
         g->gram_lds = 0; g->drow_off = 0;
         const size_t with_rows = g->prod_lds + sizeof(double) * (size_t)g->w * (qpad + PIPE_DROW_PAD);
-        if (!heavy_rows && !overlap && with_rows <= 160 * 1024) {
+        if (!overlap && with_rows <= 160 * 1024) {
             g->gram_lds = 1; g->drow_off = g->gram_off + 16 + (int)red; g->prod_lds = with_rows;
         }
         // ... and no `new` rows go to HBM either (4 KB per step at Q = 512, a fifth of the tick's memory traffic): see lazy_rows
@@ -790,6 +792,47 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         for (int i = tid + by * PIPE_BLOCK; i < N; i += PIPE_BLOCK * gy) { slot_of[i] = i; row_valid[i] = 1; }
         for (int i = tid + by * PIPE_BLOCK; i < 2 * Kb; i += PIPE_BLOCK * gy) stage[i] = N + i;
         int ovf = 0;
+        if (pa.g.rowq) {
+            // rows pulled from a queue: the initial set too — four contributions at a time from the chain's counter (the launch has
+            // more producer workgroups than the chip has CUs: a static share per wave would make the ones that wait for a CU a
+            // second round as long as the first)
+            constexpr int CH = 4;
+            int32_t *rq = pa.rowq + (size_t)rep * 2 + (t & 1);
+            for (int pulls = 0; pulls * CH <= N; ++pulls) {
+                int n0 = 0;
+                if (lane == 0) n0 = __hip_atomic_fetch_add(rq, CH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                n0 = __builtin_amdgcn_readfirstlane(n0);
+                if (n0 < 0 || n0 >= N) break;
+                const int n = n0 + lane;
+                double row[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+                if (lane < CH && n < N) {
+#pragma unroll
+                    for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+                        if (p < P) {
+                            if (a.start_from_min) row[p] = a.start_value[p];
+                            else {
+                                double u = src.at(sn.init_base + (uint64_t)p * N + n, ovf);
+                                row[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
+                            }
+                            rset[(size_t)n * P + p] = row[p];
+                        }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) row[p] = a.gen_lo[p] > 0. ? a.gen_lo[p] : 1e-9;
+                }
+                Contrib<M> mine;
+                mine.prepare(a.model, row);
+                for (int l = 0; l < CH && n0 + l < N; ++l) {
+                    const Contrib<M> c = mine.bcast(__builtin_amdgcn_readfirstlane(l));
+                    double it[QPL];
+                    RowEval<M, QPL>::run(c, qt, lane, it);
+#pragma unroll
+                    for (int j = 0; j < QPL; ++j) cache[(size_t)(n0 + l) * qpad + lane + WAVE * j] = it[j];
+                }
+            }
+            if (__any(ovf) && lane == 0) atomicOr(&pa.chains[rep].overflow, 1);
+            return;
+        }
         // contribution n = lane*nw + gw + 64*nw*i: every producer wave of the chain owns ~N/nw rows
         for (int nb = 0; nb < N; nb += nw * WAVE) {
             const int n = nb + lane * nw + gw;
@@ -1138,84 +1181,93 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         return;
     }
 
-    MCSAS_STAMP_DECL(pp0 = 0, pp1 = 0, pp2 = 0, pp3 = 0);
-    MCSAS_STAMP(pp0);
-    PIPE_TLX_MARK(pa, t, 0);
-    // ---- window w of the attempt, rows with an integral (or a smeared model).  The block owns BR = 8 rpw consecutive steps
-    // and EVERY wave works out the proposals of all of them (lane l <-> block row l: the lanes are there anyway).  With more
-    // than one row per wave the rows are dealt by predicted cost (models.h: row_cost) — wave v takes the v-th most expensive,
-    // the (16 - 1 - v)-th, the (16 + v)-th ... (boustrophedon over the cost ranking) — so that every wave carries about the
-    // same total: a worm's row costs up to five times another's (its Kuhn length sets the number of quadrature panels), and
-    // with one row per wave the tick lasts as long as the chip's most expensive row while most waves sit idle.
-    const int64_t w = (int64_t)t - sn.t_init - 1;
-    const int rpw = pa.g.rows_per_wave, buf = t & 1, BR = 8 * rpw;
-    const int kb0 = by * BR;                                      // the block's first row in the window
-    const int64_t s0 = w * Kb + kb0;
-    double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
-    int pov = 0;
     {
-        const int64_t sl = s0 + lane;
+        // ---- window w of the attempt, rows with an integral (or a smeared model): the chain's producer waves PULL rows from a queue.
+        // A row of these models costs 10^4 .. 10^5 instructions and up to five times its neighbour's (a worm's Kuhn length sets the
+        // number of quadrature panels, a cylinder's radius the Bessel function's branch): with a static deal a tick lasted as long as
+        // its unluckiest wave (13 worm chains: 0.47 of the issue rate; 256 chains, whose many blocks the dispatcher balances: 0.70).
+        //   1. the block works out the proposals of ALL Kb steps of the window, one per thread (draw, generator transform, prepare(),
+        //      predicted cost: models.h row_cost), and parks the records in LDS — 500 instructions per step against 10^5 for its row;
+        //   2. every thread ranks its step by predicted cost (most expensive first; steps behind max_iter last);
+        //   3. every wave takes the next rank from the chain's counter in device memory (one atomic per row, zeroed a tick ahead by
+        //      the scan block) until the window is handed out: longest rows first, the short ones fill the gaps.
+        // No Gram phase here: the scan block has the rows of an 8-step sub-window in its LDS anyway and takes the 28 dot products
+        // there (pipe_scan_block) — the steps of a sub-window are no longer evaluated by one workgroup.
+        const int64_t w = (int64_t)t - sn.t_init - 1;
+        const int buf = t & 1;
+        const int64_t s0 = w * Kb;
+        const int64_t left = max_iter - s0;
+        const int nvalid = left >= Kb ? Kb : (left > 0 ? (int)left : 0);
+        constexpr int CON = (int)(sizeof(Contrib<M>) / 8), REC = CON + MCSAS_MAX_ACTIVE + 2;   // Contrib | proposal values | overflow flag | cost
+        static_assert(sizeof(Contrib<M>) % 8 == 0, "Contrib record");
+        double *rec = lds + pa.g.rec_off;                         // [Kb][REC]
+        int32_t *order = reinterpret_cast<int32_t *>(rec + (size_t)Kb * REC);   // [Kb] rank -> step of the window
+        int32_t *rslot = order + Kb;                              // [Kb][2] row slot of the step's contribution, spare slot for its new row
+        for (int k = tid; k < Kb; k += PIPE_BLOCK) {
+            double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+            int pov = 0;
 #pragma unroll
-        for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
-            if (p < P) {
-                double u = 0.5;
-                if (lane < BR && sl < max_iter) u = src.at(sn.step_base + (uint64_t)sl * P + p, pov);
-                prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
-            }
-    }
-    Contrib<M> prop;
-    prop.prepare(a.model, prow);
-    // rank of my lane's row among the block's rows by predicted cost, most expensive first (ties: by row number)
-    int rank = lane;
-    if (rpw > 1) {
-        const double cst = (lane < BR && s0 + lane < max_iter) ? row_cost<M, QPL>(prop, lq) : -1.0;   // (rows behind max_iter: last)
-        rank = 0;
-        for (int j = 0; j < BR; ++j) {
-            const double cj = readlane_f64(cst, j);
-            rank += (cj > cst || (cj == cst && j < lane)) ? 1 : 0;
+            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+                if (p < P) {
+                    double u = 0.5;
+                    if (k < nvalid) u = src.at(sn.step_base + (uint64_t)(s0 + k) * P + p, pov);
+                    prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
+                }
+            Contrib<M> prop;
+            prop.prepare(a.model, prow);
+            double cost = -1.0;                                   // (steps behind max_iter: last)
+            if (k < nvalid) cost = Contrib<M>::ROW_CLASS == 2 ? row_cost<M, QPL>(prop, lq) : 0.0;
+            double tmp[CON];
+            __builtin_memcpy(tmp, &prop, sizeof(Contrib<M>));
+#pragma unroll
+            for (int i = 0; i < CON; ++i) rec[(size_t)k * REC + i] = tmp[i];
+#pragma unroll
+            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) rec[(size_t)k * REC + CON + p] = prow[p];
+            rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE] = (double)pov;
+            rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE + 1] = cost;
+            const int r = (int)((s0 + k) % N);
+            rslot[2 * k] = slot_of[r]; rslot[2 * k + 1] = stage[buf * Kb + k];
         }
-    }
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
-    PIPE_TLX_MARK(pa, t, 1);
-    auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
-    auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
-    auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
-    auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
-    // row slots of all the block's rows in one round trip (lane l <-> block row l): the row loop below then starts its loads
-    // of `old` without waiting for a dependent index load per row
-    int my_oslot = 0, my_sslot = 0;
-    if (lane < BR) {
-        int r = (int)((s0 + lane) % N);
-        my_oslot = slot_of[r]; my_sslot = stage[buf * Kb + kb0 + lane];
-    }
-    // my i-th row: the block row whose rank is 8 i + v (i even) or 8 i + 7 - v (i odd)
-    auto my_row = [&](int i) {
-        const int target = 8 * i + ((i & 1) ? 7 - wv : wv);
-        const unsigned long long mask = __ballot(lane < BR && rank == target);
-        return (int)__builtin_ctzll(mask | (1ull << 63));          // (every rank 0 .. BR-1 is taken exactly once)
-    };
-    // The `old` row of a step is read BEHIND the evaluation of its `new` row: a row with an integral takes tens of microseconds,
-    // the load two, and the sixteen or thirty-two registers a row requested ahead would occupy across the evaluation are the
-    // difference between the integrand's inner loops running from registers or from scratch.
-    int lr = my_row(0);
-    PIPE_TLX_MARK(pa, t, 2);
-    PIPE_TLX_MARK(pa, t, 3);
-    for (int i = 0; i < rpw; ++i) {
-        const int bl = __builtin_amdgcn_readfirstlane(lr);       // block row of this iteration
-        const int k = kb0 + bl;
-        const int lr_next = i + 1 < rpw ? my_row(i + 1) : lr;
-        if (s0 + bl < max_iter) {                                 // uniform in the wave (rows behind max_iter rank last)
-            const Contrib<M> cnew = prop.bcast(bl);
-            const int sslot = __builtin_amdgcn_readlane(my_sslot, bl);
+        __syncthreads();
+        for (int k = tid; k < Kb; k += PIPE_BLOCK) {
+            int rank = k;
+            if constexpr (Contrib<M>::ROW_CLASS == 2) {
+                const double cst = rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE + 1];
+                rank = 0;
+                for (int j = 0; j < Kb; ++j) {
+                    const double cj = rec[(size_t)j * REC + CON + MCSAS_MAX_ACTIVE + 1];
+                    rank += (cj > cst || (cj == cst && j < k)) ? 1 : 0;
+                }
+            }
+            order[rank] = k;
+        }
+        PIPE_LDS_BARRIER();
+        auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
+        auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
+        auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
+        auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
+        int32_t *rowq = pa.rowq + (size_t)rep * 2 + buf;
+        if (MCSAS_TUNE_BITS(a) & 16) return;                              // diagnostic: no window rows
+        for (int pulls = 0; pulls <= Kb; ++pulls) {               // (a wave can draw at most every row of the window: the loop ends whatever the counter holds)
+            int idx = 0;
+            if (lane == 0) idx = __hip_atomic_fetch_add(rowq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            idx = __builtin_amdgcn_readfirstlane(idx);
+            if (idx < 0 || idx >= nvalid) break;                  // (the ranks behind nvalid are the steps behind max_iter)
+            const int k = __builtin_amdgcn_readfirstlane(order[idx]);
+            Contrib<M> cnew;
+            {
+                double tmp[CON];
+#pragma unroll
+                for (int i = 0; i < CON; ++i) tmp[i] = readlane_f64(rec[(size_t)k * REC + i], 0);   // one address for the wave: into scalar registers
+                __builtin_memcpy(&cnew, tmp, sizeof(Contrib<M>));
+            }
+            const int oslot = __builtin_amdgcn_readfirstlane(rslot[2 * k]), sslot = __builtin_amdgcn_readfirstlane(rslot[2 * k + 1]);
             const auto nrow = cache + (size_t)sslot * qpad + lane;
             const auto dr = dwin + (size_t)k * qpad + lane;
-            // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  (Taking the
-            // sums in the scan block's pass over the row instead was measured: its single h pass is the serial part of a
-            // tick, 5x the dot-product work there cost 8 us per tick, here it is spread over every CU.)
-            // Every q slot is consumed the moment the evaluator has it (RowEval::run_each) and nothing of the row stays in registers
-            // across the evaluation of the next slot (the row arrays used to be spilled to scratch around every slot: 20-30 KB per
-            // step).  The `old` value of a slot is requested one slot ahead: it lands while that slot is evaluated.
-            const auto orow = cache + (size_t)__builtin_amdgcn_readlane(my_oslot, bl) * qpad + lane;
+            // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  Every q slot is
+            // consumed the moment the evaluator has it (RowEval::run_each) and nothing of the row stays in registers across the
+            // evaluation of the next slot; the `old` value of a slot is requested one slot ahead.
+            const auto orow = cache + (size_t)oslot * qpad + lane;
             double s1 = 0., s2 = 0., s3 = 0.;
             double o_ahead = orow[0];
             RowEval<M, QPL>::run_each(cnew, qt, lane, [&](int j, double v) {
@@ -1230,50 +1282,11 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
             });
             wave_sum3(s1, s2, s3);
             if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
-#pragma unroll
-            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
-                if (p < P) {
-                    const double v = readlane_f64(prow[p], bl);
-                    if (lane == 0) pval[k * MCSAS_MAX_ACTIVE + p] = v;
-                }
-            const int ov = __builtin_amdgcn_readlane(pov, bl);
-            if (lane == 0) povf[k] = ov;
+            if (lane < P) pval[k * MCSAS_MAX_ACTIVE + lane] = rec[(size_t)k * REC + CON + lane];
+            if (lane == 0) povf[k] = (int)rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE];
         }
-        lr = lr_next;
+        PIPE_TL_MARK(pa, t, 17);
     }
-    // ---- the sub-window's Gram block from the d rows the block has just written (workgroup-scope visibility:
-    // the barrier's fence; same CU, same L1)
-    if (MCSAS_TUNE_BITS(a) & 64) return;                                  // diagnostic: no Gram blocks
-    MCSAS_STAMP(pp1);
-    PIPE_TL_MARK(pa, t, 0);
-    __syncthreads();
-    MCSAS_STAMP(pp2);
-    PIPE_TL_MARK(pa, t, 1);
-    {
-        // (one pass over both sub-windows with six accumulators and a single run of reduction rounds was measured:
-        // no faster than one call per sub-window)
-        const int W = pa.g.w, nsb = pa.g.sub_per_block;       // the block's rows are nsb scan sub-windows of W steps
-        for (int ss = 0; ss < nsb; ++ss) {
-            const int sub = by * nsb + ss;                    // sub-window index within the window
-            const int64_t left = max_iter - (w * Kb + (int64_t)sub * W);
-            const int nvalid = left >= W ? W : (left > 0 ? (int)left : 0);
-            if (nvalid > 1)
-                pipe_prod_gram<QPL>(dwin + (size_t)sub * W * qpad, qpad, W, nvalid, lw, lds + pa.g.gram_off + 16,
-                                    glb(pa.gwin) + (((size_t)rep * 2 + buf) * Kb + (size_t)sub * W) * W);
-            if (ss + 1 < nsb) PIPE_LDS_BARRIER();             // the reduction buffer is reused
-        }
-    }
-    PIPE_TL_MARK(pa, t, 2);
-#ifdef MCSAS_STAMPS
-    MCSAS_STAMP(pp3);
-    if (by == 0 && tid == 0) {                                // wave 0 of the chain's first producer block
-        PipeChain &chs = pa.chains[rep];
-        atomicAdd((unsigned long long *)&chs.dbg[8], (unsigned long long)(pp1 - pp0));
-        atomicAdd((unsigned long long *)&chs.dbg[9], (unsigned long long)(pp2 - pp1));
-        atomicAdd((unsigned long long *)&chs.dbg[10], (unsigned long long)(pp3 - pp2));
-        atomicAdd((unsigned long long *)&chs.dbg[11], 1ull);
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------ scanner
@@ -1288,6 +1301,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
     constexpr int T = PIPE_BLOCK;
     MCSAS_GLOBAL PipeChain &ch = glb(pa.chains)[rep];
     if (ch.done) return;                                      // uniform for the block
+    if (pa.g.rowq && tid == 0) pa.rowq[(size_t)rep * 2 + (t & 1)] = 0;   // the queue of PROD(t + 2) (this launch's producers use the other parity)
     MCSAS_STAMP_DECL(sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0);
     MCSAS_STAMP(sb0);
 #ifdef MCSAS_STAMPS
@@ -1413,7 +1427,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 if (i < W * W) *reinterpret_cast<v2f64 *>(dst + i) = gtmp[x];
             }
         };
-        if (nsub > 0) { gram_fetch(0); gram_store(0); }
+        const bool gram_here = pa.g.rowq != 0;                 // rows with an integral: the Gram blocks are worked out below, from the rows in LDS
+        if (nsub > 0 && !gram_here) { gram_fetch(0); gram_store(0); }
         // ft, w ft -> LDS; the thread's own q in the apply phase: q = tid (+ 512)
         constexpr int QT = (QPL * 64 + T - 1) / T;            // q per thread in the apply phase (1 or 2)
         double wq[QT];
@@ -1461,7 +1476,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             MCSAS_STAMP(s0);
             const int k0 = s * W;
             const int cnt = (kmax_all - k0) < W ? (kmax_all - k0) : W;
-            gram_fetch(s + 1 < nsub ? s + 1 : s);              // (its LDS buffer was last read two sub-windows ago)
+            if (!gram_here) gram_fetch(s + 1 < nsub ? s + 1 : s);   // (its LDS buffer was last read two sub-windows ago)
             // ---- my rows of this sub-window: h = Σ (w ft) d, and the row itself into the LDS row buffer
             double acc[8];
 #pragma unroll
@@ -1496,9 +1511,30 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 const int c = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
                 if (lane < 8 && c < RPS && wave + 8 * c < cnt) hsub[wave + 8 * c] = tot;
             }
-            gram_store(s + 1);                                 // read at the earliest after B1 of the next sub-window
+            if (!gram_here) gram_store(s + 1);                 // read at the earliest after B1 of the next sub-window
             MCSAS_STAMP(s1);
             PIPE_LDS_BARRIER();                                            // B1: hsub, the row buffer and this sub-window's Gram block complete
+            if (gram_here) {
+                // G[a][k] = Σ_q w d_a d_k of the sub-window's (eight) rows, which are all in the row buffer now: wave a takes row a
+                // against every row, q = lane + 64 j, the eight sums reduced together.  (The producers' MFMA pass did this when one
+                // workgroup evaluated the eight steps of a sub-window; with rows pulled from a queue no workgroup has them all.)
+                if (wave < cnt) {
+                    double ga[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) ga[x] = 0.;
+#pragma unroll
+                    for (int j = 0; j < QPL; ++j) {
+                        const int iq = lane + WAVE * j;
+                        const double wa = gw_[iq] * rowbuf[(size_t)wave * qpad + iq];
+#pragma unroll
+                        for (int x = 0; x < 8; ++x) ga[x] = fma(wa, x < cnt ? rowbuf[(size_t)x * qpad + iq] : 0., ga[x]);   // (rows behind cnt: stale LDS)
+                    }
+                    const double tot = wave_sum8_transposed(ga, lane);
+                    const int c = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
+                    if (lane < 8) Gl[(size_t)(s & 1) * W * W + (size_t)wave * W + c] = tot;
+                }
+                PIPE_LDS_BARRIER();
+            }
             MCSAS_STAMP(s2);
             if (wave == 0) {
                 // ---- the W decisions of the sub-window: lane g <-> step k0 + g
@@ -1816,6 +1852,9 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
         // 32 CUs with one block per CU — two XCDs get 35 blocks and their chains take two rounds.
         const int gy = hot.prod_blocks_y;
         int rep = (b - R) / gy, y = (b - R) % gy;
+        // rows pulled from a queue: block-major over the chains (b = R + y R + rep), so that the workgroups that have to wait for a
+        // CU — the launch has more of them than the chip — are the LAST block of every chain, not all blocks of the last chains
+        if (pa.g.rowq) { rep = (b - R) % R; y = (b - R) / R; }
         if (MCSAS_TUNE_BITS(pa.c) & 128) { const int x = b & 7, j = (b - R) >> 3; rep = x + 8 * (j / gy); y = j % gy; }
         if (rep < R) pipe_prod_block<M, QPL>(pa, hot, lds, rep, y, gy, t + 1);
     }
@@ -1836,6 +1875,7 @@ __global__ void pipe_reset_kernel(const PipeArgs *pap) {
     ch.snap[0] = s; ch.snap[1] = s;
     ch.attempts = 1; ch.chi2 = 0.; ch.A = 1.; ch.t_start = wall_clock64();
     pa.chains[rep] = ch;
+    if (pa.rowq) { pa.rowq[(size_t)rep * 2] = 0; pa.rowq[(size_t)rep * 2 + 1] = 0; }
 }
 
 }  // namespace mcsas

@@ -505,15 +505,16 @@ extern "C" const char *mcsas_hip_plugin_log(void) { return g_plugin_log.c_str();
 
 // ------------------------------------------------------------------------------ host helpers
 // what the host needs to know about a model, read off its Contrib<M> (models.h) — no per-model code below this table
-struct ModelTraits { int int_div_param, rowtab, row_class; bool can_smear; int (*table_doubles)(int); };
+struct ModelTraits { int int_div_param, rowtab, row_class; bool can_smear; int (*table_doubles)(int); int contrib_doubles; };
 static ModelTraits model_traits(int model_id) {
-#define TRAITS_OF(m) {Contrib<m>::INT_DIV_PARAM, Contrib<m>::ROWTAB, Contrib<m>::ROW_CLASS, Contrib<m>::CAN_SMEAR, &Contrib<m>::table_doubles},
+#define TRAITS_OF(m) {Contrib<m>::INT_DIV_PARAM, Contrib<m>::ROWTAB, Contrib<m>::ROW_CLASS, Contrib<m>::CAN_SMEAR, &Contrib<m>::table_doubles, (int)(sizeof(Contrib<m>) / 8)},
     static const ModelTraits builtin[] = {MCSAS_FOR_MODELS(TRAITS_OF)};
 #undef TRAITS_OF
     static_assert(sizeof builtin / sizeof builtin[0] == MCSAS_MODEL_COUNT, "model_list.h and include/mcsas_hip.h disagree");
     if (model_id >= 0 && model_id < MCSAS_MODEL_COUNT) return builtin[model_id];
     const Plugin *pg = plugin_of(model_id);                                           // plugin_model.h
-    return ModelTraits{-1, 0, pg ? pg->row_class : 0, pg ? pg->can_smear : false, [](int) { return 0; }};
+    // (Contrib<MCSAS_MODEL_PLUGIN>, plugin_model.h: the full parameter vector and three doubles)
+    return ModelTraits{-1, 0, pg ? pg->row_class : 0, pg ? pg->can_smear : false, [](int) { return 0; }, MCSAS_MAX_PARAMS + 3};
 }
 static int model_int_div(const mcsas_problem *p) {
     const int i = model_traits(p->model_id).int_div_param;
@@ -741,7 +742,7 @@ struct mcsas_plan {
     PipeArgs pipe{};
     PipeChain *d_chains = nullptr;
     double *d_ft = nullptr, *d_wft = nullptr, *d_dwin = nullptr, *d_gwin = nullptr, *d_scal = nullptr, *d_pval = nullptr;
-    int32_t *d_slot_of = nullptr, *d_stage = nullptr, *d_povf = nullptr, *d_row_valid = nullptr;
+    int32_t *d_slot_of = nullptr, *d_stage = nullptr, *d_povf = nullptr, *d_row_valid = nullptr, *d_rowq = nullptr;
     uint64_t *d_timeline = nullptr;
     int32_t *h_done = nullptr;          // pinned + mapped: the scan block of the last chain to finish writes the chain count into it
     int32_t *d_done_dev = nullptr;      // the device counter behind it
@@ -995,7 +996,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         else if (waves > 1) mode = MCSAS_EXEC_WORKGROUP;
         else {
             PipeGeom pg; WgGeom wgm;
-            const bool pipe_ok = pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pg) == 0;
+            const bool pipe_ok = pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pg, model_traits(p->model_id).contrib_doubles) == 0;
             const bool wg_ok = !wide_q && wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0;
             if (!heavy_rows) {
                 // rows without an integral: the mode with the highest MEASURED rate at the nearest swept shape
@@ -1065,7 +1066,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: needs 2*window <= n_contrib and the window in LDS (nq=%d, n_contrib=%d, waves=%d)", p->nq, (int)N, waves); }
         cache_rows = (int)N + 2 * pl->wg.window;
     } else if (mode == MCSAS_EXEC_PIPELINE) {
-        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pl->pipe.g)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
+        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pl->pipe.g, model_traits(p->model_id).contrib_doubles)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
         cache_rows = (int)N + 2 * pl->pipe.g.kb;
     }
     // The chains' row blocks must not all start at the same offset modulo the memory system's interleave: with N = 400 rows of
@@ -1158,6 +1159,8 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         PCHK(pl->pool.get(&pl->d_scal, sizeof(double) * R * 2 * Kb * 4));
         PCHK(pl->pool.get(&pl->d_row_valid, sizeof(int32_t) * R * N));
         PCHK(hipMemset(pl->d_row_valid, 0, sizeof(int32_t) * R * N));
+        PCHK(pl->pool.get(&pl->d_rowq, sizeof(int32_t) * R * 2));
+        PCHK(hipMemset(pl->d_rowq, 0, sizeof(int32_t) * R * 2));
         PCHK(pl->pool.get(&pl->d_pval, sizeof(double) * R * 2 * Kb * MCSAS_MAX_ACTIVE));
         PCHK(pl->pool.get(&pl->d_povf, sizeof(int32_t) * R * 2 * Kb));
         PCHK(hipMemset(pl->d_povf, 0, sizeof(int32_t) * R * 2 * Kb));
@@ -1169,7 +1172,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
             PCHK(hipEventCreateWithFlags(&pl->evS[i], hipEventDisableTiming));
         pa.c = a;
         pa.chains = pl->d_chains; pa.ft = pl->d_ft; pa.wft = pl->d_wft; pa.slot_of = pl->d_slot_of;
-        pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.gwin = pl->d_gwin; pa.scal = pl->d_scal; pa.row_valid = pl->d_row_valid; pa.pval = pl->d_pval;
+        pa.stage_slot = pl->d_stage; pa.dwin = pl->d_dwin; pa.gwin = pl->d_gwin; pa.scal = pl->d_scal; pa.row_valid = pl->d_row_valid; pa.pval = pl->d_pval; pa.rowq = pl->d_rowq;
         PCHK(pl->pool.get(&pl->d_done_dev, sizeof(int32_t)));
         pa.povf = pl->d_povf; pa.n_done = d_done; pa.n_done_dev = pl->d_done_dev; pa.tick = 0;
         pa.timeline = nullptr; pa.timeline_tick = -100;

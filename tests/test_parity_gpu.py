@@ -328,7 +328,10 @@ def test_heavy_models_free_running_vs_the_reference_calc(tag, reps):
         assert np.abs(z).max() < 5.0 and np.sqrt(np.mean(z**2)) < 2.0, (pre, z)
         mo = np.asarray(h.moments.fields, dtype=float)
         np.testing.assert_allclose(mo[[0, 2]], g[pre + "moments"][[0, 2]], rtol=0.05 if tag != "kho" else 0.25)
-    np.testing.assert_allclose(res["fitMeasValMean"], g["fitMean"], rtol=0.05)
+    # the mean fitted curve: 5 % plus three standard errors of the two means (in the form-factor minima of the worm-like chain
+    # the reference's own three repetitions spread by 19 %, and its fit sits four sigma off the data there)
+    fit_se = np.sqrt(np.asarray(res["fitMeasValStd"])**2 / reps + g["fitStd"]**2 / ref_reps)
+    assert (np.abs(res["fitMeasValMean"] - g["fitMean"]) <= 0.05 * np.abs(g["fitMean"]) + 3. * fit_se).all()
 
 
 @pytest.mark.parametrize("mode", [engine.EXEC_PIPELINE, engine.EXEC_WAVE, engine.EXEC_WORKGROUP])
@@ -1168,12 +1171,11 @@ def test_pipeline_geometry_follows_the_chain_count():
         plan = engine.Plan(m.setup(), q, I, sig, st)
         assert plan.info["exec_mode"] == "pipeline" and plan.info["window"] == 192, (reps, plan.info)
         plan.close()
-    # Kholodenko, 600 contributions, rows of varying cost: two rows per producer wave, dealt by predicted cost.  13 chains ->
-    # 16 producer blocks of 16 rows per chain (221 blocks, one round; the window is capped at 256 steps): window 256;
-    # 50 chains -> 14 blocks per chain (750 blocks, three rounds): window 224
+    # Kholodenko, 600 contributions, rows that cost an integral: the window is as long as 2 Kb <= N allows (capped at 256 steps)
+    # whatever the chain count — the chain's producer waves pull its rows from a queue (round 4)
     g = load("g9_kho_q512.npz")
     mk, _ = make_models("kholodenko", g["spec_lo"], g["spec_hi"])
-    for reps, window in ((13, 256), (50, 224)):
+    for reps, window in ((13, 256), (50, 256), (300, 256)):
         st = engine.Settings(n_contrib=600, n_reps=reps, max_iter=10, conv_crit=0.0, max_retries=0, seed=1, exec_mode=engine.EXEC_PIPELINE)
         plan = engine.Plan(mk.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st)
         assert plan.info["window"] == window, (reps, plan.info)
@@ -1347,11 +1349,12 @@ def test_bench_workload_at_full_budget_equals_the_c_oracle_chain_by_chain():
 
 @pytest.mark.parametrize("tag", ["cyl_aspect", "kholodenko", "ellcs"])
 def test_rows_with_an_integral_give_the_same_chain_whatever_the_chain_count(tag):
-    """Pipeline mode, rows that cost an integral: the window (producer blocks per chain, rows per producer wave) follows the
-    number of chains in the launch — and nothing a chain decides may depend on it (8-step Gram blocks whatever the rows per
-    wave, running sums re-derived every 64 steps of the attempt wherever a window ends, chi²·Q carried across windows
-    exactly).  24 repetitions in one launch, in two launches of 12 and in launches of 5: bit for bit the same arrays — which is
-    what makes a device list (mcsas_problem.devices) reproduce one device for these models too."""
+    """Pipeline mode, rows that cost an integral: the producer blocks per chain follow the number of chains in the launch, and which
+    wave evaluates which row is decided at run time (the chain's waves pull rows from a queue) — nothing a chain decides may depend
+    on either (the window is fixed by the contribution count, 8-step Gram blocks taken by the scan block, running sums re-derived
+    every 64 steps of the attempt, chi²·Q carried across windows exactly).  24 repetitions in one launch, in two launches of 12 and
+    in launches of 5: bit for bit the same arrays — which is what makes a device list (mcsas_problem.devices) reproduce one device
+    for these models too — and the same again when the launch is simply repeated."""
     q, I, sig = _synthetic(128)
     lo, hi = RANDOM_RANGES[tag]
     kw = {"intDiv": 20.} if tag in ("cyl_aspect", "ellcs") else {}
@@ -1359,8 +1362,11 @@ def test_rows_with_an_integral_give_the_same_chain_whatever_the_chain_count(tag)
     st = engine.Settings(n_contrib=400, n_reps=24, max_iter=900, conv_crit=1e-9, max_retries=0, seed=21, exec_mode=engine.EXEC_PIPELINE)
     one = engine.analyse(m.setup(), q, I, sig, st)
     windows = {engine.Plan(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "n_reps": r})).info["window"] for r in (24, 12, 5)}
-    assert len(windows) > 1                                   # the geometries really differ
+    assert windows == {200}                                   # 2 Kb <= N = 400, a multiple of 8
     assert one.num_moves.min() > 0 and len(set(one.num_moves.tolist())) > 3
+    again = engine.analyse(m.setup(), q, I, sig, st)
+    for name in ("contribs", "fit", "chisq", "num_iter", "num_moves"):
+        np.testing.assert_array_equal(getattr(again, name), getattr(one, name), err_msg=name + " (same launch repeated)")
     for devs in ((0, 0), (0,) * 5):
         many = engine.analyse(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "devices": devs}))
         for name in ("contribs", "fit", "chisq", "scaling", "background", "num_iter", "num_moves"):
