@@ -104,6 +104,7 @@ struct PipeGeom {
     int32_t rowq;                 // rows with an integral (round 4): the producer waves of a chain PULL the window's rows from a queue, most expensive
                                   // first (no static deal), and the scan block works out the 8-step Gram blocks itself from the rows in its LDS
     int32_t rec_off;              // rowq: producer LDS offset (doubles) of the window's proposal records
+    int32_t help;                 // rowq: a producer block whose chain's queue is empty joins another chain's (pipe_prod_rowq)
     uint64_t prod_lds, scan_lds;
 };
 
@@ -166,7 +167,7 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     while (qpl * 64 < nq) qpl *= 2;
     if (qpl > 16) return 1;
     const int qpad = qpl * 64;
-    g->rowq = 0; g->rec_off = 0;
+    g->rowq = 0; g->rec_off = 0; g->help = 0;
     if (heavy_rows) {
         // Rows that cost an integral each (round 4).  The window is as long as 2 Kb <= N allows (a multiple of the 8-step Gram
         // blocks, at most 256 steps: one proposal per thread of the first half of a block) — it no longer follows the chain count
@@ -174,6 +175,9 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         // a queue in order of predicted cost: a wave that drew a cheap row simply comes back sooner.
         int kb = (n_contrib / 2) & ~7;
         if (kb > 256) kb = 256;
+#ifndef __HIPCC_RTC__
+        if (const char *e = getenv("MCSAS_HIP_PIPE_KB")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= kb) kb = v; }     // (measurement knob, host only)
+#endif
         if (kb < 8) return 1;
         // producer blocks per chain: enough to cover every CU by themselves — the launch then holds more workgroups than CUs, the
         // scan blocks (dispatched first) are done within a tenth of a tick, and the producer blocks that were waiting take over
@@ -186,8 +190,12 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         g->rowq = 1; g->rec_off = g->gram_off + 16;
         const size_t rec = (size_t)kb * (contrib_doubles + MCSAS_MAX_ACTIVE + 2) + ((size_t)3 * kb + 1) / 2;      // records; rank -> step and the two row slots (int32)
         g->prod_lds = sizeof(double) * ((size_t)g->rec_off + rec);
+        g->help = (n_chains > 1 && (size_t)n_chains <= 2 * rec) ? 1 : 0;       // (the helpers' table of rows left per chain takes the records' place)
+#ifndef __HIPCC_RTC__
+        if (const char *e = getenv("MCSAS_HIP_PIPE_HELP")) g->help = atoi(e) ? g->help : 0;                           // (measurement knob, host only)
+#endif
         g->scan_waves = PIPE_WAVES;
-        g->scan_lds = sizeof(double) * ((size_t)g->w * qpad + 2 * (size_t)g->w * g->w + 2 * (size_t)qpad + (size_t)g->kb * 4 + 64)
+        g->scan_lds = sizeof(double) * ((size_t)g->w * qpad + 2 * (size_t)g->w * g->w + 3 * (size_t)qpad + (size_t)g->kb * 4 + 64)
                     + sizeof(int32_t) * (4 * (size_t)g->kb + 1 + 1 + 64 + 4 + 8) + 64;
         if (g->scan_lds > 160 * 1024 || g->prod_lds > 160 * 1024) return 1;
         return 0;
@@ -745,7 +753,241 @@ __device__ __forceinline__ void pipe_gram_sum_store(int W, const double *gred, M
     }
 }
 
+// ------------------------------------------------------------------------------------ producer, rows with an integral
+// Rows of these models (or of a smeared one) cost 10^4 .. 10^5 instructions and up to five times their neighbour's (a worm's Kuhn
+// length sets the number of quadrature panels, a cylinder's radius the Bessel function's branch): with a static deal a tick lasted as
+// long as its unluckiest wave (13 worm chains: 0.47 of the issue rate; 256 chains, whose many blocks the dispatcher balances: 0.70).
+// The producer waves of a chain PULL rows instead, from a counter per chain and tick parity in device memory (PipeArgs::rowq, zeroed a
+// tick ahead by the scan block):
+//   window tick  1. the block works out the proposals of ALL Kb steps of the window, one per thread (draw, generator transform,
+//                   prepare(), predicted cost: models.h row_cost), and parks the records in LDS — 500 instructions per step against
+//                   10^5 for its row;
+//                2. every thread ranks its step by predicted cost (most expensive first; steps behind max_iter last);
+//                3. every wave takes the next rank from the counter until the window is handed out: longest rows first, the short
+//                   ones fill the gaps.
+//   initial tick the contributions of the initial set, four at a time.
+// No Gram phase here: the scan block has the rows of an 8-step sub-window in its LDS anyway and takes the 28 dot products there
+// (pipe_scan_block) — the steps of a sub-window are no longer evaluated by one workgroup.
+// One visit = one chain's queue worked on until it is empty.  `helper`: the chain is not the block's own (pipe_prod_rowq).
 template <int M, int QPL>
+__device__ __forceinline__ void pipe_rowq_visit(const PipeArgs &pa, const PipeHot &hot, double *lds, const QTables &qt, int rep, int by, int gy, int t,
+                                                const PipeSnap &sn, bool helper) {
+    const ChainArgs &a = pa.c;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int N = hot.n_contrib, P = hot.n_active, qpad = hot.qpad, Kb = hot.kb;
+    const int64_t max_iter = hot.max_iter;
+    double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad;
+    auto rset = glb(a.rset) + (size_t)rep * N * P;
+    auto cache = glb(a.cache) + (size_t)rep * a.cache_rows * qpad;
+    const DrawSource src{a.replay ? a.replay + (size_t)rep * a.replay_len : nullptr, a.replay_len, a.seed,
+                         (uint32_t)(a.rep_offset + rep)};
+    auto slot_of = glb(pa.slot_of) + (size_t)rep * N;
+    auto stage = glb(pa.stage_slot) + (size_t)rep * 2 * Kb;
+    auto row_valid = glb(pa.row_valid) + (size_t)rep * N;
+    int32_t *rowq = pa.rowq + (size_t)rep * 2 + (t & 1);
+
+    if (t == sn.t_init) {
+        // ---- initial parameter set of the attempt (mcsas.py:310-319).  (A static share per wave would make the workgroups that
+        // wait for a CU — the launch has more of them than the chip — a second round as long as the first.)
+        if (!helper) {
+            for (int i = tid + by * PIPE_BLOCK; i < N; i += PIPE_BLOCK * gy) { slot_of[i] = i; row_valid[i] = 1; }
+            for (int i = tid + by * PIPE_BLOCK; i < 2 * Kb; i += PIPE_BLOCK * gy) stage[i] = N + i;
+        }
+        int ovf = 0;
+        constexpr int CH = 4;
+        for (int pulls = 0; pulls * CH <= N; ++pulls) {
+            int n0 = 0;
+            if (lane == 0) n0 = __hip_atomic_fetch_add(rowq, CH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            n0 = __builtin_amdgcn_readfirstlane(n0);
+            if (n0 < 0 || n0 >= N) break;
+            const int n = n0 + lane;
+            double row[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+            if (lane < CH && n < N) {
+#pragma unroll
+                for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+                    if (p < P) {
+                        if (a.start_from_min) row[p] = a.start_value[p];
+                        else {
+                            double u = src.at(sn.init_base + (uint64_t)p * N + n, ovf);
+                            row[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
+                        }
+                        rset[(size_t)n * P + p] = row[p];
+                    }
+            } else {
+#pragma unroll
+                for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) row[p] = a.gen_lo[p] > 0. ? a.gen_lo[p] : 1e-9;
+            }
+            Contrib<M> mine;
+            mine.prepare(a.model, row);
+            for (int l = 0; l < CH && n0 + l < N; ++l) {
+                const Contrib<M> c = mine.bcast(__builtin_amdgcn_readfirstlane(l));
+                double it[QPL];
+                RowEval<M, QPL>::run(c, qt, lane, it);
+#pragma unroll
+                for (int j = 0; j < QPL; ++j) cache[(size_t)(n0 + l) * qpad + lane + WAVE * j] = it[j];
+            }
+        }
+        if (__any(ovf) && lane == 0) atomicOr(&pa.chains[rep].overflow, 1);
+        return;
+    }
+
+    // ---- window w of the attempt
+    const int64_t w = (int64_t)t - sn.t_init - 1;
+    const int buf = t & 1;
+    const int64_t s0 = w * Kb;
+    const int64_t left = max_iter - s0;
+    const int nvalid = left >= Kb ? Kb : (left > 0 ? (int)left : 0);
+    constexpr int CON = (int)(sizeof(Contrib<M>) / 8), REC = CON + MCSAS_MAX_ACTIVE + 2;   // Contrib | proposal values | overflow flag | cost
+    static_assert(sizeof(Contrib<M>) % 8 == 0, "Contrib record");
+    double *rec = lds + pa.g.rec_off;                         // [Kb][REC]
+    int32_t *order = reinterpret_cast<int32_t *>(rec + (size_t)Kb * REC);   // [Kb] rank -> step of the window
+    int32_t *rslot = order + Kb;                              // [Kb][2] row slot of the step's contribution, spare slot for its new row
+    for (int k = tid; k < Kb; k += PIPE_BLOCK) {
+        double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
+        int pov = 0;
+#pragma unroll
+        for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
+            if (p < P) {
+                double u = 0.5;
+                if (k < nvalid) u = src.at(sn.step_base + (uint64_t)(s0 + k) * P + p, pov);
+                prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
+            }
+        Contrib<M> prop;
+        prop.prepare(a.model, prow);
+        double cost = -1.0;                                   // (steps behind max_iter: last)
+        if (k < nvalid) cost = Contrib<M>::ROW_CLASS == 2 ? row_cost<M, QPL>(prop, lq) : 0.0;
+        double tmp[CON];
+        __builtin_memcpy(tmp, &prop, sizeof(Contrib<M>));
+#pragma unroll
+        for (int i = 0; i < CON; ++i) rec[(size_t)k * REC + i] = tmp[i];
+#pragma unroll
+        for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) rec[(size_t)k * REC + CON + p] = prow[p];
+        rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE] = (double)pov;
+        rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE + 1] = cost;
+        const int r = (int)((s0 + k) % N);
+        rslot[2 * k] = slot_of[r]; rslot[2 * k + 1] = stage[buf * Kb + k];
+    }
+    __syncthreads();
+    for (int k = tid; k < Kb; k += PIPE_BLOCK) {
+        int rank = k;
+        if constexpr (Contrib<M>::ROW_CLASS == 2) {
+            const double cst = rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE + 1];
+            rank = 0;
+            for (int j = 0; j < Kb; ++j) {
+                const double cj = rec[(size_t)j * REC + CON + MCSAS_MAX_ACTIVE + 1];
+                rank += (cj > cst || (cj == cst && j < k)) ? 1 : 0;
+            }
+        }
+        order[rank] = k;
+    }
+    PIPE_LDS_BARRIER();
+    auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
+    auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
+    auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
+    auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
+    if (MCSAS_TUNE_BITS(a) & 16) return;                                  // diagnostic: no window rows
+    for (int pulls = 0; pulls <= Kb; ++pulls) {               // (a wave can draw at most every row of the window: the loop ends whatever the counter holds)
+        int idx = 0;
+        if (lane == 0) idx = __hip_atomic_fetch_add(rowq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx < 0 || idx >= nvalid) break;                  // (the ranks behind nvalid are the steps behind max_iter)
+        const int k = __builtin_amdgcn_readfirstlane(order[idx]);
+        Contrib<M> cnew;
+        {
+            double tmp[CON];
+#pragma unroll
+            for (int i = 0; i < CON; ++i) tmp[i] = readlane_f64(rec[(size_t)k * REC + i], 0);   // one address for the wave: into scalar registers
+            __builtin_memcpy(&cnew, tmp, sizeof(Contrib<M>));
+        }
+        const int oslot = __builtin_amdgcn_readfirstlane(rslot[2 * k]), sslot = __builtin_amdgcn_readfirstlane(rslot[2 * k + 1]);
+        const auto nrow = cache + (size_t)sslot * qpad + lane;
+        const auto dr = dwin + (size_t)k * qpad + lane;
+        // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  Every q slot is
+        // consumed the moment the evaluator has it (RowEval::run_each) and nothing of the row stays in registers across the
+        // evaluation of the next slot (the row arrays used to be spilled to scratch around every slot: 20-30 KB per step); the
+        // `old` value of a slot is requested one slot ahead and lands while that slot is evaluated.
+        const auto orow = cache + (size_t)oslot * qpad + lane;
+        double s1 = 0., s2 = 0., s3 = 0.;
+        double o_ahead = orow[0];
+        RowEval<M, QPL>::run_each(cnew, qt, lane, [&](int j, double v) {
+            const int iq = lane + WAVE * j;
+            const double o = o_ahead;
+            o_ahead = orow[WAVE * (j + 1 < QPL ? j + 1 : j)];
+            nrow[WAVE * j] = v;
+            const double dj = v - o;
+            dr[WAVE * j] = dj;
+            const double wd = lw[iq] * dj;
+            s1 += wd; s2 = fma(lwI[iq], dj, s2); s3 = fma(wd, dj, s3);
+        });
+        wave_sum3(s1, s2, s3);
+        if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
+        if (lane < P) pval[k * MCSAS_MAX_ACTIVE + lane] = rec[(size_t)k * REC + CON + lane];
+        if (lane == 0) povf[k] = (int)rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE];
+    }
+}
+
+// The block's own chain first; then it HELPS.  The launch holds more producer workgroups than the chip has CUs (so that the CUs the
+// scan blocks leave after a tenth of a tick are taken over), the chains do not get their workgroups at the same time, and chains that
+// have converged — or wait for their next attempt — need none: a block whose queue is empty looks at what is left in EVERY chain's
+// queue (one chain per thread: schedule record and counter), and joins one picked with probability proportional to the rows left
+// (by a hash of the block index, so that the helpers spread like the work) if that is worth the 500 instructions per step of working
+// out that chain's proposals again.  The tick then ends when the rows of ALL chains are done, and the last chains of an analysis that
+// runs to its criterion get the whole chip.  Bounded: PIPE_HELP_TRIES visits per block, none once every queue is (nearly) empty.
+constexpr int PIPE_HELP_TRIES = 8;
+constexpr int PIPE_HELP_MIN_ROWS = 4;
+template <int M, int QPL>
+__device__ __forceinline__ void pipe_prod_rowq(const PipeArgs &pa, const PipeHot &hot, double *lds, const QTables &qt, int rep, int by, int gy, int t,
+                                               const PipeSnap &sn, bool own) {
+    const int tid = threadIdx.x, lane = tid & 63, R = hot.n_reps, N = hot.n_contrib, Kb = hot.kb;
+    if (own) pipe_rowq_visit<M, QPL>(pa, hot, lds, qt, rep, by, gy, t, sn, false);
+    if (!pa.g.help) return;
+    int32_t *box = reinterpret_cast<int32_t *>(lds + pa.g.gram_off);       // (the 16 doubles ahead of the proposal records)
+    int32_t *rem = reinterpret_cast<int32_t *>(lds + pa.g.rec_off);        // [R] rows left per chain (the records' place: pipe_geometry sets `help` only if they fit)
+    for (int tries = 0; tries < PIPE_HELP_TRIES; ++tries) {
+        __syncthreads();                                          // every wave is done with the records of the last visit
+        for (int c = tid; c < R; c += PIPE_BLOCK) {
+            int r = 0;
+            const PipeSnap cs = load_snap(&hot.chains[c].snap[t & 1]);
+            if (cs.alive && t >= cs.t_init) {
+                int total = N;
+                if (t > cs.t_init) {
+                    const int64_t left = hot.max_iter - ((int64_t)t - cs.t_init - 1) * Kb;
+                    total = left >= Kb ? Kb : (left > 0 ? (int)left : 0);
+                }
+                r = total - __hip_atomic_load(pa.rowq + (size_t)c * 2 + (t & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r < PIPE_HELP_MIN_ROWS) r = 0;
+            }
+            rem[c] = r;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int chunk = (R + 63) / 64, lo = lane * chunk, hi = min(R, lo + chunk);
+            int sum = 0;
+            for (int c = lo; c < hi; ++c) sum += rem[c];
+            int incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            if (lane == 0) box[0] = -1;
+            if (total > 0) {
+                const uint32_t hsh = ((uint32_t)blockIdx.x * 2654435761u) ^ ((uint32_t)(tries + 1) * 0x9E3779B9u) ^ ((uint32_t)t * 0x85EBCA6Bu);
+                const int pos = (int)((hsh >> 8) % (uint32_t)total);
+                if (pos >= incl - sum && pos < incl) {            // exactly one lane
+                    int acc = incl - sum, pick = lo;
+                    for (int c = lo; c < hi; ++c) { if (pos < acc + rem[c]) { pick = c; break; } acc += rem[c]; }
+                    box[0] = pick;
+                }
+            }
+        }
+        __syncthreads();
+        const int target = box[0];
+        if (target < 0) break;
+        const PipeSnap cs = load_snap(&hot.chains[target].snap[t & 1]);
+        pipe_rowq_visit<M, QPL>(pa, hot, lds, qt, target, by, gy, t, cs, true);
+    }
+}
+
+template <int M, int QPL, bool RQ>                            // RQ: rows pulled from a queue (PipeGeom::rowq), a kernel of its own
 __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHot &hot, double *lds, int rep, int by, int gy, int t) {
     const ChainArgs &a = pa.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -762,7 +1004,8 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     }
     PIPE_TL_CLOCK(c_entry);                                   // (hot arguments in registers, loads issued)
     const PipeSnap sn = load_snap(&hot.chains[rep].snap[t & 1]);
-    if (!sn.alive || t < sn.t_init) return;
+    const bool own = sn.alive && t >= sn.t_init;
+    if (!own && !(RQ && pa.g.help)) return;                   // (row queues: a block whose chain has nothing to do this tick helps the others)
     PIPE_TL_CLOCK(c_snap);
 
     double *lq = lds, *lw = lds + qpad, *lwI = lds + 2 * qpad, *lq3 = lds + 3 * qpad, *tab = lds + 4 * qpad;
@@ -778,6 +1021,7 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
     PIPE_TL_CLOCK(c_bar);
     PIPE_TL_PUT(pa, t, 22, c_entry); PIPE_TL_PUT(pa, t, 23, c_snap); PIPE_TL_PUT(pa, t, 24, c_tab); PIPE_TL_PUT(pa, t, 25, c_bar);
     const QTables qt = make_qtables<M>(a.model, lq, lq3, tab);
+    if constexpr (RQ) { pipe_prod_rowq<M, QPL>(pa, hot, lds, qt, rep, by, gy, t, sn, own); return; }
     auto rset = glb(a.rset) + (size_t)rep * N * P;
     auto cache = glb(a.cache) + (size_t)rep * a.cache_rows * qpad;
     const DrawSource src{a.replay ? a.replay + (size_t)rep * a.replay_len : nullptr, a.replay_len, a.seed,
@@ -792,47 +1036,6 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         for (int i = tid + by * PIPE_BLOCK; i < N; i += PIPE_BLOCK * gy) { slot_of[i] = i; row_valid[i] = 1; }
         for (int i = tid + by * PIPE_BLOCK; i < 2 * Kb; i += PIPE_BLOCK * gy) stage[i] = N + i;
         int ovf = 0;
-        if (pa.g.rowq) {
-            // rows pulled from a queue: the initial set too — four contributions at a time from the chain's counter (the launch has
-            // more producer workgroups than the chip has CUs: a static share per wave would make the ones that wait for a CU a
-            // second round as long as the first)
-            constexpr int CH = 4;
-            int32_t *rq = pa.rowq + (size_t)rep * 2 + (t & 1);
-            for (int pulls = 0; pulls * CH <= N; ++pulls) {
-                int n0 = 0;
-                if (lane == 0) n0 = __hip_atomic_fetch_add(rq, CH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                n0 = __builtin_amdgcn_readfirstlane(n0);
-                if (n0 < 0 || n0 >= N) break;
-                const int n = n0 + lane;
-                double row[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
-                if (lane < CH && n < N) {
-#pragma unroll
-                    for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
-                        if (p < P) {
-                            if (a.start_from_min) row[p] = a.start_value[p];
-                            else {
-                                double u = src.at(sn.init_base + (uint64_t)p * N + n, ovf);
-                                row[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
-                            }
-                            rset[(size_t)n * P + p] = row[p];
-                        }
-                } else {
-#pragma unroll
-                    for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) row[p] = a.gen_lo[p] > 0. ? a.gen_lo[p] : 1e-9;
-                }
-                Contrib<M> mine;
-                mine.prepare(a.model, row);
-                for (int l = 0; l < CH && n0 + l < N; ++l) {
-                    const Contrib<M> c = mine.bcast(__builtin_amdgcn_readfirstlane(l));
-                    double it[QPL];
-                    RowEval<M, QPL>::run(c, qt, lane, it);
-#pragma unroll
-                    for (int j = 0; j < QPL; ++j) cache[(size_t)(n0 + l) * qpad + lane + WAVE * j] = it[j];
-                }
-            }
-            if (__any(ovf) && lane == 0) atomicOr(&pa.chains[rep].overflow, 1);
-            return;
-        }
         // contribution n = lane*nw + gw + 64*nw*i: every producer wave of the chain owns ~N/nw rows
         for (int nb = 0; nb < N; nb += nw * WAVE) {
             const int n = nb + lane * nw + gw;
@@ -1181,117 +1384,11 @@ __device__ __forceinline__ void pipe_prod_block(const PipeArgs &pa, const PipeHo
         return;
     }
 
-    {
-        // ---- window w of the attempt, rows with an integral (or a smeared model): the chain's producer waves PULL rows from a queue.
-        // A row of these models costs 10^4 .. 10^5 instructions and up to five times its neighbour's (a worm's Kuhn length sets the
-        // number of quadrature panels, a cylinder's radius the Bessel function's branch): with a static deal a tick lasted as long as
-        // its unluckiest wave (13 worm chains: 0.47 of the issue rate; 256 chains, whose many blocks the dispatcher balances: 0.70).
-        //   1. the block works out the proposals of ALL Kb steps of the window, one per thread (draw, generator transform, prepare(),
-        //      predicted cost: models.h row_cost), and parks the records in LDS — 500 instructions per step against 10^5 for its row;
-        //   2. every thread ranks its step by predicted cost (most expensive first; steps behind max_iter last);
-        //   3. every wave takes the next rank from the chain's counter in device memory (one atomic per row, zeroed a tick ahead by
-        //      the scan block) until the window is handed out: longest rows first, the short ones fill the gaps.
-        // No Gram phase here: the scan block has the rows of an 8-step sub-window in its LDS anyway and takes the 28 dot products
-        // there (pipe_scan_block) — the steps of a sub-window are no longer evaluated by one workgroup.
-        const int64_t w = (int64_t)t - sn.t_init - 1;
-        const int buf = t & 1;
-        const int64_t s0 = w * Kb;
-        const int64_t left = max_iter - s0;
-        const int nvalid = left >= Kb ? Kb : (left > 0 ? (int)left : 0);
-        constexpr int CON = (int)(sizeof(Contrib<M>) / 8), REC = CON + MCSAS_MAX_ACTIVE + 2;   // Contrib | proposal values | overflow flag | cost
-        static_assert(sizeof(Contrib<M>) % 8 == 0, "Contrib record");
-        double *rec = lds + pa.g.rec_off;                         // [Kb][REC]
-        int32_t *order = reinterpret_cast<int32_t *>(rec + (size_t)Kb * REC);   // [Kb] rank -> step of the window
-        int32_t *rslot = order + Kb;                              // [Kb][2] row slot of the step's contribution, spare slot for its new row
-        for (int k = tid; k < Kb; k += PIPE_BLOCK) {
-            double prow[MCSAS_MAX_ACTIVE] = {0., 0., 0., 0.};
-            int pov = 0;
-#pragma unroll
-            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p)
-                if (p < P) {
-                    double u = 0.5;
-                    if (k < nvalid) u = src.at(sn.step_base + (uint64_t)(s0 + k) * P + p, pov);
-                    prow[p] = gen_transform(a.gen_kind[p], u) * (a.gen_hi[p] - a.gen_lo[p]) + a.gen_lo[p];
-                }
-            Contrib<M> prop;
-            prop.prepare(a.model, prow);
-            double cost = -1.0;                                   // (steps behind max_iter: last)
-            if (k < nvalid) cost = Contrib<M>::ROW_CLASS == 2 ? row_cost<M, QPL>(prop, lq) : 0.0;
-            double tmp[CON];
-            __builtin_memcpy(tmp, &prop, sizeof(Contrib<M>));
-#pragma unroll
-            for (int i = 0; i < CON; ++i) rec[(size_t)k * REC + i] = tmp[i];
-#pragma unroll
-            for (int p = 0; p < MCSAS_MAX_ACTIVE; ++p) rec[(size_t)k * REC + CON + p] = prow[p];
-            rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE] = (double)pov;
-            rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE + 1] = cost;
-            const int r = (int)((s0 + k) % N);
-            rslot[2 * k] = slot_of[r]; rslot[2 * k + 1] = stage[buf * Kb + k];
-        }
-        __syncthreads();
-        for (int k = tid; k < Kb; k += PIPE_BLOCK) {
-            int rank = k;
-            if constexpr (Contrib<M>::ROW_CLASS == 2) {
-                const double cst = rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE + 1];
-                rank = 0;
-                for (int j = 0; j < Kb; ++j) {
-                    const double cj = rec[(size_t)j * REC + CON + MCSAS_MAX_ACTIVE + 1];
-                    rank += (cj > cst || (cj == cst && j < k)) ? 1 : 0;
-                }
-            }
-            order[rank] = k;
-        }
-        PIPE_LDS_BARRIER();
-        auto dwin = glb(pa.dwin) + ((size_t)rep * 2 + buf) * Kb * qpad;
-        auto scal = glb(pa.scal) + ((size_t)rep * 2 + buf) * Kb * 4;
-        auto pval = glb(pa.pval) + ((size_t)rep * 2 + buf) * Kb * MCSAS_MAX_ACTIVE;
-        auto povf = glb(pa.povf) + ((size_t)rep * 2 + buf) * Kb;
-        int32_t *rowq = pa.rowq + (size_t)rep * 2 + buf;
-        if (MCSAS_TUNE_BITS(a) & 16) return;                              // diagnostic: no window rows
-        for (int pulls = 0; pulls <= Kb; ++pulls) {               // (a wave can draw at most every row of the window: the loop ends whatever the counter holds)
-            int idx = 0;
-            if (lane == 0) idx = __hip_atomic_fetch_add(rowq, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            idx = __builtin_amdgcn_readfirstlane(idx);
-            if (idx < 0 || idx >= nvalid) break;                  // (the ranks behind nvalid are the steps behind max_iter)
-            const int k = __builtin_amdgcn_readfirstlane(order[idx]);
-            Contrib<M> cnew;
-            {
-                double tmp[CON];
-#pragma unroll
-                for (int i = 0; i < CON; ++i) tmp[i] = readlane_f64(rec[(size_t)k * REC + i], 0);   // one address for the wave: into scalar registers
-                __builtin_memcpy(&cnew, tmp, sizeof(Contrib<M>));
-            }
-            const int oslot = __builtin_amdgcn_readfirstlane(rslot[2 * k]), sslot = __builtin_amdgcn_readfirstlane(rslot[2 * k + 1]);
-            const auto nrow = cache + (size_t)sslot * qpad + lane;
-            const auto dr = dwin + (size_t)k * qpad + lane;
-            // d = new - old and the three sums that do not depend on ft: a = Σ w d, e = Σ wI d, g = Σ w d².  Every q slot is
-            // consumed the moment the evaluator has it (RowEval::run_each) and nothing of the row stays in registers across the
-            // evaluation of the next slot; the `old` value of a slot is requested one slot ahead.
-            const auto orow = cache + (size_t)oslot * qpad + lane;
-            double s1 = 0., s2 = 0., s3 = 0.;
-            double o_ahead = orow[0];
-            RowEval<M, QPL>::run_each(cnew, qt, lane, [&](int j, double v) {
-                const int iq = lane + WAVE * j;
-                const double o = o_ahead;
-                o_ahead = orow[WAVE * (j + 1 < QPL ? j + 1 : j)];
-                nrow[WAVE * j] = v;
-                const double dj = v - o;
-                dr[WAVE * j] = dj;
-                const double wd = lw[iq] * dj;
-                s1 += wd; s2 = fma(lwI[iq], dj, s2); s3 = fma(wd, dj, s3);
-            });
-            wave_sum3(s1, s2, s3);
-            if (lane == 0) { scal[k * 4 + 0] = s1; scal[k * 4 + 1] = s2; scal[k * 4 + 2] = s3; }
-            if (lane < P) pval[k * MCSAS_MAX_ACTIVE + lane] = rec[(size_t)k * REC + CON + lane];
-            if (lane == 0) povf[k] = (int)rec[(size_t)k * REC + CON + MCSAS_MAX_ACTIVE];
-        }
-        PIPE_TL_MARK(pa, t, 17);
-    }
 }
 
 // ------------------------------------------------------------------------------------ scanner
 // LDS: two Gram blocks, ft and w*ft, the window's scalars, h of the current sub-window, flags and slot tables
-template <int M, int QPL, int RPS>                             // RPS = rows per wave and sub-window (W / 8), compile time: see `request`
+template <int M, int QPL, int RPS, bool RQ>                    // RPS = rows per wave and sub-window (W / 8), compile time: see `request`
 __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds, int rep, int t, int stop_now) {
     static_assert(PIPE_GRAM_TILES_PER_ROUND * 256 == PIPE_BLOCK, "Gram reduction maps one thread to one tile element");
     const ChainArgs &a = pa.c;
@@ -1301,7 +1398,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
     constexpr int T = PIPE_BLOCK;
     MCSAS_GLOBAL PipeChain &ch = glb(pa.chains)[rep];
     if (ch.done) return;                                      // uniform for the block
-    if (pa.g.rowq && tid == 0) pa.rowq[(size_t)rep * 2 + (t & 1)] = 0;   // the queue of PROD(t + 2) (this launch's producers use the other parity)
+    if (RQ && tid == 0) pa.rowq[(size_t)rep * 2 + (t & 1)] = 0;   // the queue of PROD(t + 2) (this launch's producers use the other parity)
     MCSAS_STAMP_DECL(sb0 = 0, sb1 = 0, sb2 = 0, sb3 = 0);
     MCSAS_STAMP(sb0);
 #ifdef MCSAS_STAMPS
@@ -1320,6 +1417,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
     int32_t *lacc = lslot + Kb;                               // [Kb + 1] accepted steps of this window, count in lacc[Kb]
     int32_t *sacc = lacc + Kb + 1;                            // [1 + 64] this sub-window: count, then the accepted steps' offsets in it
     int32_t *ctl = sacc + 1 + 64;                             // [4]: [2] = live
+    double *lwq = reinterpret_cast<double *>((reinterpret_cast<unsigned long long>(ctl + 4) + 7ull) & ~7ull);   // [qpad] w (row queues: the Gram blocks are taken here)
     auto gft = glb(pa.ft) + (size_t)rep * qpad, gwft = glb(pa.wft) + (size_t)rep * qpad;
     auto rset = glb(a.rset) + (size_t)rep * N * P;
     auto cache = glb(a.cache) + (size_t)rep * a.cache_rows * qpad;
@@ -1427,7 +1525,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                 if (i < W * W) *reinterpret_cast<v2f64 *>(dst + i) = gtmp[x];
             }
         };
-        const bool gram_here = pa.g.rowq != 0;                 // rows with an integral: the Gram blocks are worked out below, from the rows in LDS
+        constexpr bool gram_here = RQ;                         // rows with an integral: the Gram blocks are worked out below, from the rows in LDS
         if (nsub > 0 && !gram_here) { gram_fetch(0); gram_store(0); }
         // ft, w ft -> LDS; the thread's own q in the apply phase: q = tid (+ 512)
         constexpr int QT = (QPL * 64 + T - 1) / T;            // q per thread in the apply phase (1 or 2)
@@ -1436,7 +1534,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
         for (int x = 0; x < QT; ++x) {
             const int i = tid + T * x;
             wq[x] = 0.;
-            if (i < qpad) { wq[x] = gw_[i]; lft[i] = gft[i]; lwft[i] = gwft[i]; }
+            if (i < qpad) { wq[x] = gw_[i]; lft[i] = gft[i]; lwft[i] = gwft[i]; if constexpr (RQ) lwq[i] = wq[x]; }
         }
         if (tid < kmax_all) {                                  // Kb <= 256 < threads
             osub[tid] = povf[tid];
@@ -1514,7 +1612,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             if (!gram_here) gram_store(s + 1);                 // read at the earliest after B1 of the next sub-window
             MCSAS_STAMP(s1);
             PIPE_LDS_BARRIER();                                            // B1: hsub, the row buffer and this sub-window's Gram block complete
-            if (gram_here) {
+            if constexpr (gram_here) {
                 // G[a][k] = Σ_q w d_a d_k of the sub-window's (eight) rows, which are all in the row buffer now: wave a takes row a
                 // against every row, q = lane + 64 j, the eight sums reduced together.  (The producers' MFMA pass did this when one
                 // workgroup evaluated the eight steps of a sub-window; with rows pulled from a queue no workgroup has them all.)
@@ -1522,12 +1620,14 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     double ga[8];
 #pragma unroll
                     for (int x = 0; x < 8; ++x) ga[x] = 0.;
-#pragma unroll
+                    // (not unrolled over q: sixteen slots of nine operands each in flight took the scan loop's registers — 929 spills at
+                    // Q = 1024 and a sub-window in 40 us instead of 5.  Rows behind cnt are stale LDS: their sums are never read.)
+#pragma nounroll
                     for (int j = 0; j < QPL; ++j) {
                         const int iq = lane + WAVE * j;
-                        const double wa = gw_[iq] * rowbuf[(size_t)wave * qpad + iq];
+                        const double wa = lwq[iq] * rowbuf[(size_t)wave * qpad + iq];
 #pragma unroll
-                        for (int x = 0; x < 8; ++x) ga[x] = fma(wa, x < cnt ? rowbuf[(size_t)x * qpad + iq] : 0., ga[x]);   // (rows behind cnt: stale LDS)
+                        for (int x = 0; x < 8; ++x) ga[x] = fma(wa, rowbuf[(size_t)x * qpad + iq], ga[x]);
                     }
                     const double tot = wave_sum8_transposed(ga, lane);
                     const int c = 4 * (lane & 1) + 2 * ((lane >> 1) & 1) + ((lane >> 2) & 1);
@@ -1815,7 +1915,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
 
 // ------------------------------------------------------------------------------------ one tick
 // launch t: blocks [0, R) do SCAN(t) (skipped for t < 0), the others PROD(t + 1)
-template <int M, int QPL>
+template <int M, int QPL, bool RQ>
 __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *pap, const int tick, const int stop_now, const PipeHot hot) {
     // The argument block lives in device memory and is read where it is needed: passed by value it
     // would sit in SGPRs for the whole kernel (600+ bytes) and the scan loop would run on spilled
@@ -1837,8 +1937,9 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
     if (b < R) {
         if (t >= 0) {
             // rows per wave and sub-window: uniform for the launch; the host only picks combinations instantiated here
-            switch (hot.w_sub >> 3) {
-#define PIPE_SCAN_CASE(r) case r: if constexpr (r * QPL <= PIPE_MAX_ROW_DOUBLES) pipe_scan_block<M, QPL, r>(pa, lds, b, t, stop_now); break;
+            if constexpr (RQ) pipe_scan_block<M, QPL, 1, true>(pa, lds, b, t, stop_now);       // (sub-windows of 8 steps)
+            else switch (hot.w_sub >> 3) {
+#define PIPE_SCAN_CASE(r) case r: if constexpr (r * QPL <= PIPE_MAX_ROW_DOUBLES) pipe_scan_block<M, QPL, r, false>(pa, lds, b, t, stop_now); break;
                 PIPE_SCAN_CASE(1) PIPE_SCAN_CASE(2) PIPE_SCAN_CASE(3) PIPE_SCAN_CASE(4) PIPE_SCAN_CASE(6) PIPE_SCAN_CASE(8)
 #undef PIPE_SCAN_CASE
                 default: break;
@@ -1854,9 +1955,9 @@ __global__ __launch_bounds__(PIPE_BLOCK) void pipe_tick_kernel(const PipeArgs *p
         int rep = (b - R) / gy, y = (b - R) % gy;
         // rows pulled from a queue: block-major over the chains (b = R + y R + rep), so that the workgroups that have to wait for a
         // CU — the launch has more of them than the chip — are the LAST block of every chain, not all blocks of the last chains
-        if (pa.g.rowq) { rep = (b - R) % R; y = (b - R) / R; }
+        if constexpr (RQ) { rep = (b - R) % R; y = (b - R) / R; }
         if (MCSAS_TUNE_BITS(pa.c) & 128) { const int x = b & 7, j = (b - R) >> 3; rep = x + 8 * (j / gy); y = j % gy; }
-        if (rep < R) pipe_prod_block<M, QPL>(pa, hot, lds, rep, y, gy, t + 1);
+        if (rep < R) pipe_prod_block<M, QPL, RQ>(pa, hot, lds, rep, y, gy, t + 1);
     }
 }
 

@@ -446,10 +446,10 @@ static int plugin_wide_function(int model_id, int qpl, hipFunction_t *fn) {
     snprintf(k, sizeof k, "wide %d", qpl);
     return plugin_function(model_id, k, {e}, e, fn);
 }
-static int plugin_pipe_function(int model_id, int qpl, hipFunction_t *fn) {
+static int plugin_pipe_function(int model_id, int qpl, bool rowq, hipFunction_t *fn) {
     char e[128], k[32];
-    snprintf(e, sizeof e, "mcsas::pipe_tick_kernel<MCSAS_MODEL_PLUGIN, %d>", qpl);
-    snprintf(k, sizeof k, "pipe %d", qpl);
+    snprintf(e, sizeof e, "mcsas::pipe_tick_kernel<MCSAS_MODEL_PLUGIN, %d, %s>", qpl, rowq ? "true" : "false");
+    snprintf(k, sizeof k, "pipe %d %d", qpl, rowq ? 1 : 0);
     return plugin_function(model_id, k, {e}, e, fn);
 }
 static int plugin_wave_function(int model_id, int qpl, bool cache, hipFunction_t *fn) {
@@ -806,14 +806,14 @@ static int plan_activate_slot(mcsas_plan *pl, int k) {
 }
 
 // kernel lookups, one translation unit per model (kern_wave.hip / kern_wg.hip)
-#define DECL_K(m) void *mcsas_wave_kernel_m##m(int, bool); void *mcsas_wg_kernel_m##m(int); void *mcsas_wide_kernel_m##m(int); void *mcsas_pipe_tick_kernel_m##m(int);
+#define DECL_K(m) void *mcsas_wave_kernel_m##m(int, bool); void *mcsas_wg_kernel_m##m(int); void *mcsas_wide_kernel_m##m(int); void *mcsas_pipe_tick_kernel_m##m(int, bool);
 MCSAS_FOR_MODELS(DECL_K)
 #undef DECL_K
 void *mcsas_pipe_reset_kernel();
 
-static void *pipe_tick_kernel_for(int model, int qpl) {
+static void *pipe_tick_kernel_for(int model, int qpl, bool rowq) {
     switch (model) {
-#define CASE_K(m) case m: return mcsas_pipe_tick_kernel_m##m(qpl);
+#define CASE_K(m) case m: return mcsas_pipe_tick_kernel_m##m(qpl, rowq);
         MCSAS_FOR_MODELS(CASE_K)
 #undef CASE_K
         default: return nullptr;
@@ -1145,7 +1145,7 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         }
     } else {
         if (plugin) {
-            rc = plugin_pipe_function(p->model_id, qpl, &pl->plugin_fn);
+            rc = plugin_pipe_function(p->model_id, qpl, pl->pipe.g.rowq != 0, &pl->plugin_fn);
             if (rc) { mcsas_hip_plan_destroy(pl); return rc; }
         }
         PipeArgs &pa = pl->pipe;
@@ -1204,7 +1204,7 @@ static int pipeline_launch(mcsas_plan *pl, hipStream_t st) {
     pa.c = pl->args;                                     // picks up reseed()
     pa.c.cache_rows = pl->args.cache_rows;
     const int R = pl->prob.n_reps, Kb = pa.g.kb;
-    void *tick = pl->plugin_fn ? nullptr : pipe_tick_kernel_for(pl->prob.model_id, pl->qpl), *reset = mcsas_pipe_reset_kernel();
+    void *tick = pl->plugin_fn ? nullptr : pipe_tick_kernel_for(pl->prob.model_id, pl->qpl, pa.g.rowq != 0), *reset = mcsas_pipe_reset_kernel();
     if (!tick && !pl->plugin_fn) return fail(MCSAS_EINVAL, "no pipeline kernel for model %d qpl %d", pl->prob.model_id, pl->qpl);
     const size_t lds = std::max(pa.g.prod_lds, pa.g.scan_lds);
     if (tick && lds > 64 * 1024) HIPCHK(hipFuncSetAttribute(tick, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
