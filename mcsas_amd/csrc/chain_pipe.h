@@ -170,11 +170,15 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     g->rowq = 0; g->rec_off = 0; g->help = 0;
     if (heavy_rows) {
         // Rows that cost an integral each (round 4).  The window is as long as 2 Kb <= N allows (a multiple of the 8-step Gram
-        // blocks, at most 256 steps: one proposal per thread of the first half of a block) — it no longer follows the chain count
+        // blocks, at most 512 steps: one proposal per thread of a block) — it no longer follows the chain count
         // —, every chain gets the producer blocks that are left beside the scan blocks, and their waves pull the window's rows from
         // a queue in order of predicted cost: a wave that drew a cheap row simply comes back sooner.
         int kb = (n_contrib / 2) & ~7;
-        if (kb > 256) kb = 256;
+        int cap = PIPE_BLOCK;                                  // (one proposal per thread; 13 worm chains: 296 steps per window 4.12e6 steps/s, 256: 3.86e6)
+#ifndef __HIPCC_RTC__
+        if (const char *e = getenv("MCSAS_HIP_PIPE_KB_CAP")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= PIPE_BLOCK) cap = v; }   // (measurement knob, host only)
+#endif
+        if (kb > cap) kb = cap;
 #ifndef __HIPCC_RTC__
         if (const char *e = getenv("MCSAS_HIP_PIPE_KB")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= kb) kb = v; }     // (measurement knob, host only)
 #endif

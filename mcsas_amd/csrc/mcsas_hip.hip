@@ -1005,14 +1005,15 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
                 // repetitions).  A device with another CU count is asked at the repetition count that loads it the same.
                 mode = auto_mode_light(qpad, p->n_contrib, (double)p->n_reps * 256.0 / (double)n_cus, pipe_ok, wg_ok);
             } else {
-                // Rows that cost an integral each: the pipeline at every chain count up to where the chains alone fill the SIMDs twice
-                // over (round 4, tools/sweep_heavy_modes2.sh, 6000-10 000 steps per chain: cylinders 5.5 / 5.6 / 5.5e6 steps/s in the
-                // pipeline at 256 / 512 / 1024 chains against 4.8 / 4.8 / 4.7e6 per workgroup and 1.3 / 2.5 / 4.9e6 per wavefront;
-                // Kholodenko 4.6 / 4.6 / 4.5 / 4.5e6 at 256 ... 2048 against 4.0 / 4.0 / 3.9 / 3.8e6 and 1.0 / 1.9 / 3.8 / 4.8e6;
-                // core-shell ellipsoids at 400 chains 3.7e6 against 1.5e6 per wavefront — round 2's thresholds (pipeline up to 192
-                // chains, workgroup up to 1024) predate the cost-balanced deal of the rows).  Units of a 256-CU device.
+                // Rows that cost an integral each: the pipeline at every chain count, since its producer waves pull the rows from a
+                // queue (round 4, tools/sweep_heavy_modes2.sh, profiles/r04_heavy_modes.txt; steps/s pipeline | one wavefront per chain:
+                // cylinders 5.2e6 | 1.3e6 at 300 chains, 6.0e6 | 3.6e6 at 2048, 5.7e6 | 4.4e6 at 4096; Kholodenko 4.4e6 | 0.9e6 at 300,
+                // 5.2e6 | 4.8e6 at 2048, 4.7e6 | 4.5e6 at 4096; core-shell ellipsoids 2.5e6 | 0.7e6 at 300 chains x 1000 steps,
+                // 3.8e6 | 3.6e6 at 2048 x 3000; the workgroup mode in between at best).  Where the pipeline's geometry does not fit
+                // (fewer than 16 contributions), the older rule: one wavefront per chain from where the chains alone fill the
+                // SIMDs, a workgroup per chain below.  Units of a 256-CU device.
                 const double r_eff = (double)p->n_reps * 256.0 / (double)n_cus;
-                if (r_eff < 1536. && pipe_ok) mode = MCSAS_EXEC_PIPELINE;
+                if (pipe_ok) mode = MCSAS_EXEC_PIPELINE;
                 else if (r_eff >= 1024.) mode = MCSAS_EXEC_WAVE;
                 else if (wg_ok) mode = MCSAS_EXEC_WORKGROUP;
                 else mode = MCSAS_EXEC_WAVE;

@@ -1001,17 +1001,18 @@ def test_device_histogram_equals_the_two_step_host_path(tag):
 
 
 def test_auto_mode_for_rows_with_an_integral():
-    """MCSAS_EXEC_AUTO for models whose rows cost an integral (round 4 sweep, tools/sweep_heavy_modes2.sh): the pipeline up to where the
-    chains alone fill the SIMDs twice over — BASELINE's totals of configs 3 and 4 on one GPU (200 / 400 chains) included —, one
-    wavefront per chain beyond."""
+    """MCSAS_EXEC_AUTO for models whose rows cost an integral (round 4 sweep, tools/sweep_heavy_modes2.sh, profiles/r04_heavy_modes.txt):
+    the pipeline at every chain count — BASELINE's totals of configs 3 and 4 on one GPU (200 / 400 chains) included; where its
+    geometry does not fit (fewer than 16 contributions; nor does the workgroup mode's then) one wavefront per chain."""
     q, I, sig = _synthetic(128)
     m, _ = make_models("cyl_aspect", *RANDOM_RANGES["cyl_aspect"], intDiv=20.)
-    for reps, want in ((13, "pipeline"), (200, "pipeline"), (400, "pipeline"), (1024, "pipeline"), (2048, "wave")):
-        st = engine.Settings(n_contrib=64, n_reps=reps, max_iter=50, conv_crit=0.0, max_retries=0, seed=1)
+    for ncontrib, reps, want in ((64, 13, "pipeline"), (64, 200, "pipeline"), (64, 400, "pipeline"), (64, 2048, "pipeline"),
+                                 (12, 13, "wave"), (12, 2048, "wave")):
+        st = engine.Settings(n_contrib=ncontrib, n_reps=reps, max_iter=50, conv_crit=0.0, max_retries=0, seed=1)
         plan = engine.Plan(m.setup(), q, I, sig, st)
         if engine.device_count() and plan.info["exec_mode"] != want:
             import torch
-            assert torch.cuda.get_device_properties(0).multi_processor_count != 256, (reps, plan.info)   # (thresholds scale with the CU count)
+            assert torch.cuda.get_device_properties(0).multi_processor_count != 256, (ncontrib, reps, plan.info)   # (thresholds scale with the CU count)
         plan.close()
 
 
@@ -1171,11 +1172,11 @@ def test_pipeline_geometry_follows_the_chain_count():
         plan = engine.Plan(m.setup(), q, I, sig, st)
         assert plan.info["exec_mode"] == "pipeline" and plan.info["window"] == 192, (reps, plan.info)
         plan.close()
-    # Kholodenko, 600 contributions, rows that cost an integral: the window is as long as 2 Kb <= N allows (capped at 256 steps)
-    # whatever the chain count — the chain's producer waves pull its rows from a queue (round 4)
+    # Kholodenko, 600 contributions, rows that cost an integral: the window is as long as 2 Kb <= N allows (296 steps; the cap is one
+    # step per thread of a workgroup, 512) whatever the chain count — the chain's producer waves pull its rows from a queue (round 4)
     g = load("g9_kho_q512.npz")
     mk, _ = make_models("kholodenko", g["spec_lo"], g["spec_hi"])
-    for reps, window in ((13, 256), (50, 256), (300, 256)):
+    for reps, window in ((13, 296), (50, 296), (300, 296)):
         st = engine.Settings(n_contrib=600, n_reps=reps, max_iter=10, conv_crit=0.0, max_retries=0, seed=1, exec_mode=engine.EXEC_PIPELINE)
         plan = engine.Plan(mk.setup(FakeData(g["data_q"])), g["data_q"], g["data_I"], g["data_sigma"], st)
         assert plan.info["window"] == window, (reps, plan.info)
