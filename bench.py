@@ -700,7 +700,7 @@ class ClockSampler(object):
 
     def __enter__(self):
         import threading
-        if self.cards:
+        if self.cards and not os.environ.get("MCSAS_BENCH_NO_CLOCKS"):     # (measurement knob: is the sampling itself visible in the rate?)
             self._th = threading.Thread(target=self._loop, daemon=True); self._th.start()
         return self
 
