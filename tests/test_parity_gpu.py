@@ -1374,6 +1374,48 @@ def test_rows_with_an_integral_give_the_same_chain_whatever_the_chain_count(tag)
             np.testing.assert_array_equal(getattr(many, name), getattr(one, name), err_msg="%s with %d blocks" % (name, len(devs)))
 
 
+@pytest.mark.parametrize("tag,nq,N,R,steps", [("cyl_aspect", 100, 48, 7, 120), ("ellcs", 100, 48, 7, 120), ("kholodenko", 40, 32, 5, 60)])
+def test_rows_with_an_integral_retries_and_uneven_chain_ends_follow_the_oracle(tag, nq, N, R, steps):
+    """McSAS.analyse's retry loop (mcsas.py:220-246) for models whose rows cost an integral, in the pipeline's row-queue kernels:
+    seven (five) free-running chains, up to three attempts of 120 (60) steps each, with a criterion that about half of the first
+    attempts reach — so chains converge in different windows, fail and start again from a new initial set (pulled from the chain's
+    initialisation queue), or give up, while the producer blocks of the chains that are through join the queues of the others.
+    Every chain against the oracle walking the same Philox stream attempt after attempt: attempts, iterations and moves of the
+    last attempt, draws, parameter sets exact; chi² 1e-7.  The wavefront mode must give the same arrays."""
+    q, I, sig = _synthetic(nq)
+    lo, hi = RANDOM_RANGES[tag]
+    kw = {"intDiv": 20.} if tag in ("cyl_aspect", "ellcs") else {}
+    m, spec = make_models(tag, lo, hi, **kw)
+    retries, seed = 2, 4242
+    lim = ([I.min(), I.max()], [q.min(), q.max()])
+    # criterion: the median chi² the first attempts end at with none
+    first = [O.mc_fit(spec, q, I, sig, lim[0], lim[1], O.Settings(n_contrib=N, n_reps=1, max_iter=steps, conv_crit=0.0),
+                      O.PhiloxStream(seed, r), method="closed").conval for r in range(R)]
+    crit = float(np.median(first)) * 1.001                    # (the median IS one chain's final chi²: no tie with its last step)
+    ost = O.Settings(n_contrib=N, n_reps=1, max_iter=steps, conv_crit=crit)
+    refs = []
+    for r in range(R):
+        stream, att = O.PhiloxStream(seed, r), 0
+        while True:
+            ref = O.mc_fit(spec, q, I, sig, lim[0], lim[1], ost, stream, method="closed")
+            att += 1
+            if ref.conval <= crit or att > retries:
+                break
+        refs.append((att, ref))
+    assert len({a for a, _ in refs}) > 1 and any(ref.conval <= crit for _, ref in refs)
+    out = {}
+    for mode in (engine.EXEC_PIPELINE, engine.EXEC_WAVE):
+        st = engine.Settings(n_contrib=N, n_reps=R, max_iter=steps, conv_crit=crit, max_retries=retries, seed=seed, exec_mode=mode)
+        res = out[mode] = engine.analyse(m.setup(), q, I, sig, st)
+        for r, (att, ref) in enumerate(refs):
+            assert res.attempts[r] == att and res.num_iter[r] == ref.num_iter and res.num_moves[r] == ref.num_moves, (mode, r)
+            assert res.converged[r] == (1 if ref.conval <= crit else 0)
+            np.testing.assert_allclose(res.contribs[:, :, r], ref.rset, rtol=1e-12)
+            np.testing.assert_allclose(res.chisq[r], ref.conval, rtol=1e-7)
+    for name in ("contribs", "num_iter", "num_moves", "draws", "attempts", "converged"):
+        np.testing.assert_array_equal(getattr(out[engine.EXEC_PIPELINE], name), getattr(out[engine.EXEC_WAVE], name), err_msg=name)
+
+
 def test_plugin_model_with_can_smear_matches_the_reference_smeared_intensities():
     """A plug-in that declares canSmear (`#define MCSAS_PLUGIN_CAN_SMEAR 1`, plus `canSmear = True` on the model class) is
     smeared like the built-in models: the reference's smeared sphere intensities (fixture g7, slit and pinhole trapezoid,
