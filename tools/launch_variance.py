@@ -3,7 +3,7 @@
 made unless KEEP=1), n launches each — is the 3.41 / 3.52 ms split between runs a property of the process or of the plan's memory?
 usage: tools/launch_variance.py [plans] [launches]"""
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import mcsas_amd
 from mcsas_amd import engine
