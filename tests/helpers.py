@@ -166,6 +166,29 @@ __device__ double mcsas_plugin_formfactor(double q, const double *p) {
 }
 
 
+PLUGIN_SOURCES["elliso"] = r"""
+// models/ellipsoidsisotropic.py:51-81, written the plain way: the orientation average as a loop inside the form factor;
+// p = (a, useAspect, c, aspect, intDiv, sld).  A row of this model costs an integral per q point:
+#define MCSAS_PLUGIN_ROW_CLASS 1
+__device__ double mcsas_plugin_volume(const double *p) { const double rc = p[1] != 0. ? p[0] * p[3] : p[2]; return 4. / 3. * mcsas::PI * (p[0] * p[0]) * rc; }
+__device__ double mcsas_plugin_absvolume(const double *p) { return mcsas_plugin_volume(p) * (p[5] * p[5]); }
+__device__ double mcsas_plugin_surface(const double *p) { return 0.; }
+__device__ double mcsas_plugin_formfactor(double q, const double *p) {
+    const double ra = p[0], rc = p[1] != 0. ? p[0] * p[3] : p[2];
+    const int K = (int)p[4];
+    double sum = 0.;
+    for (int k = 0; k < K; ++k) {
+        const double al = (mcsas::PI / 2.) * (double)k / (double)(K - 1);       // np.linspace(0, pi/2, intDiv)
+        double sa, ca, sx, cx;
+        sincos(al, &sa, &ca);
+        const double x = q * sqrt(ra * ra * (sa * sa) + rc * rc * (ca * ca));
+        sincos(x, &sx, &cx);
+        const double f = 3. * (sx - x * cx) / (x * x * x);
+        sum += f * f * sa;
+    }
+    return sqrt(sum / (double)K);
+}
+"""
 PLUGIN_SOURCES["sphere"] = r"""
 // models/sphere.py:37-63; p = (radius, sld); canSmear = True
 #define MCSAS_PLUGIN_CAN_SMEAR 1

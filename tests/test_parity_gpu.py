@@ -1416,6 +1416,47 @@ def test_rows_with_an_integral_retries_and_uneven_chain_ends_follow_the_oracle(t
         np.testing.assert_array_equal(getattr(out[engine.EXEC_PIPELINE], name), getattr(out[engine.EXEC_WAVE], name), err_msg=name)
 
 
+def test_plugin_model_with_an_integral_runs_the_row_queue_kernels():
+    """A plug-in that declares `#define MCSAS_PLUGIN_ROW_CLASS 1` (its form factor loops over orientations: isotropic ellipsoids,
+    models/ellipsoidsisotropic.py:51-81, written the plain way) is spread over the chip like the built-in models with an
+    integral — `pipe_tick_kernel<MCSAS_MODEL_PLUGIN, QPL, true>` compiled at run time, rows pulled from the chain's queue, blocks
+    helping each other.  Its intensities equal the oracle's (1e-9), its free-running chains are the same arrays in the pipeline,
+    wavefront and workgroup modes, and they follow the oracle on the same Philox streams decision for decision."""
+    from helpers import plugin_twin
+    lo, hi = RANDOM_RANGES["elliso"]
+    m, spec = make_models("elliso", lo, hi, intDiv=24.)
+    plugin_twin(m, "elliso")
+    setup = m.setup()
+    assert setup.model_id >= engine.MODEL_PLUGIN0
+    q, I, sig = _synthetic(100)
+    rs = np.random.RandomState(3)
+    pars = np.stack([10 ** rs.uniform(np.log10(a), np.log10(b), 9) for a, b in zip(lo, hi)], axis=1)
+    cum, v, w, s_, rows = engine.model_calc(setup, q, pars, 0.6666666, want_rows=True)
+    ref_it, ref_v = O.model_calc(spec, q, pars, 0.6666666)[:2]
+    np.testing.assert_allclose(cum, ref_it, rtol=1e-9)
+    np.testing.assert_allclose(v, ref_v, rtol=1e-12)
+    N, R, steps, seed = 48, 5, 150, 808
+    out = {}
+    for mode in (engine.EXEC_PIPELINE, engine.EXEC_WAVE, engine.EXEC_WORKGROUP):
+        st = engine.Settings(n_contrib=N, n_reps=R, max_iter=steps, conv_crit=1e-9, max_retries=0, seed=seed, exec_mode=mode)
+        plan = engine.Plan(setup, q, I, sig, st)
+        assert plan.info["exec_mode"] == {engine.EXEC_PIPELINE: "pipeline", engine.EXEC_WAVE: "wave", engine.EXEC_WORKGROUP: "workgroup"}[mode]
+        if mode == engine.EXEC_PIPELINE:
+            assert plan.info["window"] == 24                   # 2 Kb <= N: the row-queue geometry (8-step sub-windows)
+        plan.launch(); out[mode] = plan.fetch(); plan.close()
+    for mode in (engine.EXEC_WAVE, engine.EXEC_WORKGROUP):
+        for name in ("contribs", "num_iter", "num_moves", "draws"):
+            np.testing.assert_array_equal(getattr(out[mode], name), getattr(out[engine.EXEC_PIPELINE], name), err_msg=name)
+    ost = O.Settings(n_contrib=N, n_reps=1, max_iter=steps, conv_crit=1e-9)
+    res = out[engine.EXEC_PIPELINE]
+    for r in range(R):
+        ref = O.mc_fit(spec, q, I, sig, [I.min(), I.max()], [q.min(), q.max()], ost, O.PhiloxStream(seed, r), method="closed")
+        assert res.num_moves[r] == ref.num_moves and res.num_iter[r] == ref.num_iter
+        np.testing.assert_allclose(res.contribs[:, :, r], ref.rset, rtol=1e-12)
+        np.testing.assert_allclose(res.chisq[r], ref.conval, rtol=1e-7)
+    assert res.num_moves.min() > 5
+
+
 def test_plugin_model_with_can_smear_matches_the_reference_smeared_intensities():
     """A plug-in that declares canSmear (`#define MCSAS_PLUGIN_CAN_SMEAR 1`, plus `canSmear = True` on the model class) is
     smeared like the built-in models: the reference's smeared sphere intensities (fixture g7, slit and pinhole trapezoid,
