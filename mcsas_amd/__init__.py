@@ -11,7 +11,7 @@ from .parameter import (Parameter, FitParameter, RandomUniform, RandomExponentia
                         RandomExponential1, RandomExponential2, RandomExponential3, Histogram)
 from .scatteringmodels import (ScatteringModel, SASModel, SASModelData, Sphere,                   # noqa: F401
                                CylindersIsotropic, EllipsoidalCoreShell, Kholodenko, EllipsoidsIsotropic,
-                               SphericalCoreShell, GaussianChain, LMADenseSphere, setup_from_model)
+                               SphericalCoreShell, GaussianChain, LMADenseSphere, CylindersRadiallyIsotropic, setup_from_model)
 from .dataobj import SASData, SASConfig, TrapezoidSmearing, GaussianSmearing, SmearArgs                                                                      # noqa: F401
 from .series import run_series                                                                    # noqa: F401
 from .mcsas import McSAS                                                                          # noqa: F401

@@ -254,6 +254,65 @@ class LMADenseSphere(SASModel):
         self.radius.setActive(True)
 
 
+def _cyl_radially_isotropic_source(psi_range):
+    """HIP text of models/cylindersradiallyisotropic.py:49-81 for the run-time plug-in path (INTEGRATION.md "Models of the user's
+    own"): the in-plane orientation average is a loop inside the form factor, over psi = numpy.linspace(*psiAngle.valueRange(),
+    psiAngleDivisions) — the range is the PARAMETER'S valueRange at the time of the call, like the reference, hence part of the text."""
+    lo, hi = (repr(float(x)) for x in psi_range)
+    return r"""
+// models/cylindersradiallyisotropic.py:49-81; p = (radius, aspect, psiAngle, psiAngleDivisions, sld)
+#define MCSAS_PLUGIN_ROW_CLASS 1
+__device__ double mcsas_plugin_volume(const double *p) { return mcsas::PI * (p[0] * p[0]) * (2. * p[0] * p[1]); }
+__device__ double mcsas_plugin_absvolume(const double *p) { return mcsas_plugin_volume(p) * (p[4] * p[4]); }
+__device__ double mcsas_plugin_surface(const double *p) { return 0.; }
+__device__ double mcsas_plugin_formfactor(double q, const double *p) {
+    const int K = (int)p[3];
+    const double lo = %s, hi = %s, step = (hi - lo) / (double)(K > 1 ? K - 1 : 1);
+    double sum = 0.;
+    for (int k = 0; k < K; ++k) {
+        const double psi = (k == K - 1 && K > 1 ? hi : lo + step * (double)k) - p[2];     // numpy.linspace, minus the rotation
+        double sa, ca;
+        sincos(psi, &sa, &ca);
+        const double xr = fabs(q * (p[0] * sa)), xl = q * (p[0] * p[1] * ca);           // J1(x) / x is even
+        const double f = 2. * mcsas::j1_fast(xr) / xr * sin(xl) / xl;
+        sum += f * f;
+    }
+    return sqrt(sum / (double)K);
+}
+""" % (lo, hi)
+
+
+class CylindersRadiallyIsotropic(SASModel):
+    """models/cylindersradiallyisotropic.py:14-83 ("completed but not verified" there; of the reference's three cylinder variants
+    outside its verified set the one that runs as written).  No built-in kernel id: its form factor reaches the library as HIP
+    text (`hipSource`) and runs the row-queue kernels compiled at run time, like a model of the user's own."""
+    shortName = "Radially (in-plane) isotropic cylinders"
+    model_id = None
+    parameters = (
+        _fp("radius", 1. * NM, displayName="Cylinder radius", generator=RandomExponential,
+            valueRange=(0.1 * NM, np.inf), activeRange=(0.1 * NM, 1e3 * NM)),
+        _fp("aspect", 10.0, displayName="Aspect ratio L/(2R) of the cylinder", generator=RandomUniform,
+            valueRange=(0.1, np.inf), activeRange=(1.0, 20.)),
+        _fp("psiAngle", 0.17, displayName="in-plane cylinder rotation", generator=RandomUniform,
+            valueRange=(0.01, 2 * np.pi + 0.01)),
+        _p("psiAngleDivisions", 303., displayName="in-plane angle divisions", valueRange=(1, np.inf)),
+        _p("sld", 1e-6 * SLD_A2, displayName="scattering length density difference", valueRange=(0., np.inf)),
+    )
+
+    def __init__(self):
+        super().__init__()
+        self.radius.setActive(True)
+        self.aspect.setActive(False)
+        self.psiAngle.setActive(True)
+
+    @property
+    def hipSource(self):
+        return _cyl_radially_isotropic_source(self.psiAngle.valueRange())
+
+
+# reference class name -> HIP text of the models that ship as run-time plug-ins (a reference object of that class flattens like ours)
+SHIPPED_PLUGINS = {"CylindersRadiallyIsotropic": lambda model: _cyl_radially_isotropic_source(model.psiAngle.valueRange())}
+
 # reference class name -> kernel id (FindModels walks models/*.py, utils/findmodels.py:120-186)
 MODEL_IDS = {"Sphere": engine.MODEL_SPHERE, "CylindersIsotropic": engine.MODEL_CYL_ISO,
              "EllipsoidalCoreShell": engine.MODEL_ELL_CS, "Kholodenko": engine.MODEL_KHOLODENKO,
@@ -268,6 +327,8 @@ def setup_from_model(model, data=None) -> engine.ModelSetup:
     mid = getattr(model, "model_id", None)
     if mid is None:
         mid = MODEL_IDS.get(type(model).__name__)
+    if mid is None and not isinstance(getattr(model, "hipSource", None), str) and type(model).__name__ in SHIPPED_PLUGINS:
+        mid = engine.compile_plugin(SHIPPED_PLUGINS[type(model).__name__](model))
     if mid is None and isinstance(getattr(model, "hipSource", None), str):
         # a model of the user's own (the reference: any models/*.py, utils/findmodels.py:120-186): its form factor as HIP
         # source text, compiled at run time into the wave-per-chain kernel (engine.compile_plugin)

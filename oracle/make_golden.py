@@ -768,8 +768,9 @@ def gen_param_declarations():
     — the mirror classes in mcsas_amd/scatteringmodels and setup_from_model are checked against this."""
     import json
     out = {}
+    from mcsas.models.cylindersradiallyisotropic import CylindersRadiallyIsotropic
     classes = (Sphere, CylindersIsotropic, EllipsoidalCoreShell, Kholodenko, EllipsoidsIsotropic,
-               SphericalCoreShell, GaussianChain, LMADenseSphere)
+               SphericalCoreShell, GaussianChain, LMADenseSphere, CylindersRadiallyIsotropic)
     for cls in classes:
         m = cls()
         plist = []
@@ -987,6 +988,57 @@ def gen_free_running_heavy(which=("cyl", "ellcs", "kho")):
               (tag, out["wall_s"], out["numIter"], out["scaling"], out["background"]))
 
 
+def gen_cyl_radially_isotropic():
+    """G18: the one of the reference's three "not verified / unfinished" cylinder variants that runs as written
+    (models/cylindersradiallyisotropic.py; cylindersisotropicaspect.py and cylindersradiallyisotropictilted.py raise NameError on
+    their first call) — form factor / calc vectors and one short mcFit chain, for the product's run-time plug-in of it."""
+    from mcsas.models.cylindersradiallyisotropic import CylindersRadiallyIsotropic
+    out = {}
+    def fix_div(mm):
+        # (the float default breaks numpy.linspace on numpy >= 2, like intDiv: fix_intdiv)
+        mm.psiAngleDivisions.setValue(304); mm.psiAngleDivisions.setValue(303)
+    m = CylindersRadiallyIsotropic()
+    fix_div(m)
+    names = ["radius", "psiAngle"]
+    psets = [[1e-9, 0.17], [5e-9, 1.3], [2.5e-8, 3.0], [1e-7, 5.9], [3e-10, 0.02]]
+    q = np.logspace(7, np.log10(3e9), 48)
+    d = sasdata(q * 1e-9, np.ones_like(q), 0.01 * np.ones_like(q))
+    qq = np.array(d.q, dtype=float)
+    ds = QOnly(qq)
+    ff = []
+    for pv in psets:
+        for n, v in zip(names, pv):
+            getattr(m, n).setValue(v)
+        ff.append(np.array(m.formfactor(ds), dtype=float))
+    cexp = 0.6666666
+    md = m.calc(d, np.array(psets, dtype=float), cexp)
+    out.update(q=qq, pset=np.array(psets, dtype=float), ff=np.array(ff), cumInt=np.array(md.cumInt), vset=np.array(md.vset),
+               wset=np.array(md.wset), sset=np.array(md.sset), comp_exp=cexp,
+               rows=np.array([np.array(m.calc(d, np.array([pv], dtype=float), cexp).cumInt) for pv in psets]),
+               psi_range=np.array(m.psiAngle.valueRange(), dtype=float), aspect=float(m.aspect()), sld=float(m.sld()),
+               divisions=float(m.psiAngleDivisions()))
+    np.savez_compressed(os.path.join(OUT, "g18_cylradiso_models.npz"), **out)
+    # one short chain, like the other models outside the BASELINE configs (gen_trajectories: short_traj)
+    rs = np.random.RandomState(1801)
+    q_nm = np.logspace(np.log10(0.02), np.log10(2.0), 40)
+    dtmp = sasdata(q_nm, np.ones(40), 0.01 * np.ones(40))
+    model = CylindersRadiallyIsotropic()
+    fix_div(model)
+    lo, hi = [1e-9, 0.05], [5e-8, 6.0]
+    for n, l, h in zip(names, lo, hi):
+        getattr(model, n).setActive(True)
+        getattr(model, n).setActiveRange((l, h))
+    truth = np.stack([rs.uniform(3e-9, 2e-8, 30), rs.uniform(0.1, 6.0, 30)], axis=1)
+    It = np.array(model.calc(dtmp, truth, cexp).cumInt)
+    It = It / It.max() * 1e3
+    dd = sasdata(q_nm, It * (1 + 0.01 * rs.normal(size=40)), 0.01 * It)
+    algo = new_algo(numContribs=40, numReps=1, maxIterations=250, convergenceCriterion=1e-9)
+    algo.model = model; algo.data = dd
+    spec = dict(model="cylradiso", n_contrib=40, lo=lo, hi=hi, gen=[1, 0], comp_exp=cexp, max_iter=250, conv_crit=1e-9,
+                aspect=model.aspect(), sld=model.sld(), divisions=model.psiAngleDivisions())
+    save_traj("g18_cylradiso_q40.npz", data_vectors(dd), spec, run_mcfit(algo, 40, 1802))
+
+
 def gen_converging_trajectories(which=("cyl", "ellcs", "posbg")):
     """G17 — replayed mcFit chains that END BY CONVERGENCE (mcsas.py:355: `conval > convergenceCriterion` fails) for the cases
     G4 only covers with fixed budgets: a model with an orientation integral (cylinders and core-shell ellipsoids of G16's curves,
@@ -1057,3 +1109,5 @@ if __name__ == "__main__":
         gen_converging_trajectories()
     if "converge_posbg" in which:
         gen_converging_trajectories(("posbg",))
+    if "cylradiso" in which or not sys.argv[1:]:
+        gen_cyl_radially_isotropic()

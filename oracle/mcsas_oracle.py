@@ -26,8 +26,10 @@ _trapz = getattr(np, "trapezoid", None) or np.trapz
 
 # ----------------------------------------------------------------------------- model registry
 SPHERE, CYL_ISO, ELL_CS, KHOLODENKO, ELL_ISO, SPH_CS, GAUSS_CHAIN, LMA_SPHERE = 0, 1, 2, 3, 4, 5, 6, 7
+CYL_RAD_ISO = 8            # (oracle-side id only: the product runs this model as a run-time plug-in)
 MODEL_IDS = {"sphere": SPHERE, "cyl": CYL_ISO, "ellcs": ELL_CS, "kholodenko": KHOLODENKO,
-             "elliso": ELL_ISO, "sphcs": SPH_CS, "gausschain": GAUSS_CHAIN, "lmasphere": LMA_SPHERE}
+             "elliso": ELL_ISO, "sphcs": SPH_CS, "gausschain": GAUSS_CHAIN, "lmasphere": LMA_SPHERE,
+             "cylradiso": CYL_RAD_ISO}
 
 GEN_UNIFORM, GEN_EXP1, GEN_EXP2, GEN_EXP3 = 0, 1, 2, 3
 
@@ -41,6 +43,7 @@ PARAM_NAMES = {
     SPH_CS: ("radius", "t", "eta_c", "eta_s", "eta_sol"),              # sphericalcoreshell.py:22-43
     GAUSS_CHAIN: ("rg", "bp", "etas", "k"),                            # gaussianchain.py:27-48
     LMA_SPHERE: ("radius", "volFrac", "mf", "sld"),                    # lmadensesphere.py:26-55
+    CYL_RAD_ISO: ("radius", "aspect", "psiAngle", "psiAngleDivisions", "sld"),   # cylindersradiallyisotropic.py:20-41
 }
 PARAM_DEFAULTS = {
     SPHERE: (10e-9, 1e-6 * 1e20),
@@ -51,6 +54,7 @@ PARAM_DEFAULTS = {
     SPH_CS: (1e-9, 1e-9, 3.16e-6 * 1e20, 2.53e-6 * 1e20, 0.0),
     GAUSS_CHAIN: (1e-9, 100e-9, 1e-6 * 1e20, 1.0),
     LMA_SPHERE: (1e-9, 0.10, -1.0, 1e-6 * 1e20),
+    CYL_RAD_ISO: (1e-9, 10.0, 0.17, 303.0, 1e-6 * 1e20),
 }
 # valueRange (clip range applied by Parameter.setValue, bases/algorithm/parameter.py:405-414,489-495)
 PARAM_VALUE_RANGE = {
@@ -62,6 +66,7 @@ PARAM_VALUE_RANGE = {
     SPH_CS: ((0.0, np.inf),) * 5,
     GAUSS_CHAIN: ((0.0, np.inf),) * 4,
     LMA_SPHERE: ((0.0, np.inf), (0.001e-2, 1.0), (-1.0, 1e6), (0.0, np.inf)),
+    CYL_RAD_ISO: ((0.1e-9, np.inf), (0.1, np.inf), (0.01, 2 * np.pi + 0.01), (1.0, np.inf), (0.0, np.inf)),
 }
 PARAM_DEFAULT_GEN = {
     SPHERE: {"radius": GEN_UNIFORM},
@@ -72,6 +77,7 @@ PARAM_DEFAULT_GEN = {
     SPH_CS: {"radius": GEN_EXP1, "t": GEN_EXP1},
     GAUSS_CHAIN: {"rg": GEN_EXP1, "bp": GEN_UNIFORM, "etas": GEN_UNIFORM, "k": GEN_UNIFORM},
     LMA_SPHERE: {"radius": GEN_UNIFORM, "volFrac": GEN_UNIFORM},
+    CYL_RAD_ISO: {"radius": GEN_EXP1, "aspect": GEN_UNIFORM, "psiAngle": GEN_UNIFORM},
 }
 
 
@@ -184,6 +190,16 @@ def ff_ellipsoids_isotropic(q, ra, rc, int_div):
     qrp = np.outer(q, np.sqrt(ra**2 * np.sin(al)**2 + rc**2 * np.cos(al)**2))
     fsplit = 3. * (np.sin(qrp) - qrp * np.cos(qrp)) / (qrp**3.)
     return np.sqrt(np.mean(fsplit**2 * np.sin(al), axis=1))
+
+
+def ff_cylinders_radially_isotropic(q, radius, aspect, psi_angle, divisions, psi_range):
+    """models/cylindersradiallyisotropic.py:49-74: the in-plane orientation average over psi = linspace(valueRange of psiAngle)."""
+    from scipy.special import j1
+    psi = np.linspace(psi_range[0], psi_range[1], int(divisions))
+    qrs = np.outer(q, radius * np.sin(psi - psi_angle))
+    qlc = np.outer(q, radius * aspect * np.cos(psi - psi_angle))
+    fsplit = 2. * j1(qrs) / qrs * np.sin(qlc) / qlc
+    return np.sqrt(np.mean(fsplit**2, axis=1))
 
 
 def ff_spherical_core_shell(q, r, t, eta_c, eta_s, eta_sol):
@@ -359,6 +375,12 @@ def calc_intensity(spec: ModelSpec, q, row, comp_exp):
         v = vol * sld**2
         s = 0
         ff = ff_ellipsoids_isotropic(q, ra, rc, int_div)
+    elif mid == CYL_RAD_ISO:
+        r, aspect, psi_a, div, sld = p
+        vol = np.pi * r**2 * (2. * r * aspect)                 # cylindersradiallyisotropic.py:76-78
+        v = vol * sld**2                                       # :80-81
+        s = 0
+        ff = ff_cylinders_radially_isotropic(q, r, aspect, psi_a, div, PARAM_VALUE_RANGE[CYL_RAD_ISO][2])
     elif mid == SPH_CS:
         r, t, eta_c, eta_s, eta_sol = p
         vol = 4. / 3 * np.pi * (r + t)**3                      # sphericalcoreshell.py:71-73

@@ -25,6 +25,8 @@ CASES = {
     "sphcs": dict(cls=mcsas_amd.SphericalCoreShell, omodel="sphcs", active=["radius", "t"]),
     "gausschain": dict(cls=mcsas_amd.GaussianChain, omodel="gausschain", active=["rg", "bp"]),
     "lmasphere": dict(cls=mcsas_amd.LMADenseSphere, omodel="lmasphere", active=["radius", "volFrac"]),
+    # (no built-in kernel: the product runs it as a run-time plug-in, rows with an integral)
+    "cylradiso": dict(cls=mcsas_amd.CylindersRadiallyIsotropic, omodel="cylradiso", active=["radius", "psiAngle"]),
 }
 GEN_CLS = {0: mcsas_amd.RandomUniform, 1: mcsas_amd.RandomExponential, 2: mcsas_amd.RandomExponential2,
            3: mcsas_amd.RandomExponential3}
@@ -72,6 +74,8 @@ def traj_setup(name):
         extra.update(etas=float(g["spec_etas"]), k=float(g["spec_k"]))
     if model == "lmasphere":
         extra.update(sld=float(g["spec_sld"]), mf=float(g["spec_mf"]))
+    if model == "cylradiso":
+        extra.update(aspect=float(g["spec_aspect"]), sld=float(g["spec_sld"]), psiAngleDivisions=float(g["spec_divisions"]))
     m, spec = make_models(model, g["spec_lo"], g["spec_hi"], [int(x) for x in g["spec_gen"]], **extra)
     flags = dict(find_bg=bool(int(g["spec_find_bg"])) if "spec_find_bg" in g else True,
                  pos_bg=bool(int(g["spec_pos_bg"])) if "spec_pos_bg" in g else False,

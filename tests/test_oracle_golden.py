@@ -20,7 +20,7 @@ def spec_for(tag, lo=None, hi=None, gen=None, **extra):
     return make_models(tag, lo, hi, gen, **extra)[1]
 
 
-@pytest.mark.parametrize("tag", list(MODEL_CASES))
+@pytest.mark.parametrize("tag", [t for t in MODEL_CASES if t != "cylradiso"])      # (cylradiso: G18, below)
 def test_g1_g2_model_vectors(tag):
     g = load("g12_models.npz")
     spec = spec_for(tag)
@@ -37,6 +37,22 @@ def test_g1_g2_model_vectors(tag):
     np.testing.assert_allclose(vset, g[tag + "_vset"], rtol=tol)
     np.testing.assert_allclose(wset, g[tag + "_wset"], rtol=tol)
     np.testing.assert_allclose(sset, g[tag + "_sset"], rtol=tol)
+
+
+def test_g18_radially_isotropic_cylinders_vectors():
+    """models/cylindersradiallyisotropic.py (G18, oracle/make_golden.py gen_cyl_radially_isotropic): formfactor and calc of the
+    reference against the restatement."""
+    g = load("g18_cylradiso_models.npz")
+    spec = spec_for("cylradiso", aspect=float(g["aspect"]), sld=float(g["sld"]), psiAngleDivisions=float(g["divisions"]))
+    np.testing.assert_allclose(g["psi_range"], O.PARAM_VALUE_RANGE[O.CYL_RAD_ISO][2], rtol=0)
+    q, pset, c = g["q"], g["pset"], float(g["comp_exp"])
+    for row, ff_ref, it_ref in zip(pset, g["ff"], g["rows"]):
+        it, v, w, s = O.calc_intensity(spec, q, row, c)
+        np.testing.assert_allclose(it, it_ref, rtol=1e-13)
+        np.testing.assert_allclose(np.sqrt(it / w), np.abs(ff_ref), rtol=1e-12)
+    cum, vset, wset, sset = O.model_calc(spec, q, pset, c)
+    for got, name in ((cum, "cumInt"), (vset, "vset"), (wset, "wset"), (sset, "sset")):
+        np.testing.assert_allclose(got, g[name], rtol=1e-13)
 
 
 def test_g6_generators():
@@ -92,7 +108,9 @@ TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q5
         "g14_sphere_q512_long.npz", "g14_sphere_q512_converge.npz",
         # round 4: chains the reference ENDS BY CONVERGENCE (criterion 1) for models with an orientation integral (cylinders 6228
         # steps, core-shell ellipsoids 1887 steps; 100 q x 200 contributions) and with positiveBackground (sphere, criterion 2, 5768 steps)
-        "g17_cyl_q100_converge.npz", "g17_ellcs_q100_converge.npz", "g17_sphere_q100_posbg_converge.npz"]
+        "g17_cyl_q100_converge.npz", "g17_ellcs_q100_converge.npz", "g17_sphere_q100_posbg_converge.npz",
+        # round 4: radially isotropic cylinders (the reference's "not verified" variant that runs as written), 40 q x 40 x 250 steps
+        "g18_cylradiso_q40.npz"]
 
 
 def test_g17_positive_background_chain_that_only_minpack_follows():

@@ -44,6 +44,30 @@ def test_model_calc_vs_reference_vectors(tag):
     assert md.numParams == m.activeParamCount()
 
 
+def test_radially_isotropic_cylinders_plugin_vs_reference_vectors():
+    """mcsas_amd.CylindersRadiallyIsotropic (models/cylindersradiallyisotropic.py, shipped as a run-time plug-in with an orientation
+    loop in its form factor) against the reference's own formfactor / calc vectors (G18); a reference-shaped object of that class
+    name flattens to the same plug-in (setup_from_model: SHIPPED_PLUGINS)."""
+    g = load("g18_cylradiso_models.npz")
+    m, spec = make_models("cylradiso", aspect=float(g["aspect"]), sld=float(g["sld"]), psiAngleDivisions=float(g["divisions"]))
+    setup = m.setup()
+    assert setup.model_id >= engine.MODEL_PLUGIN0
+    q, pset, c = g["q"], g["pset"], float(g["comp_exp"])
+    cum, v, w, s, rows = engine.model_calc(setup, q, pset, c, want_rows=True)
+    np.testing.assert_allclose(rows, g["rows"], rtol=1e-9)
+    np.testing.assert_allclose(cum, g["cumInt"], rtol=1e-9)
+    np.testing.assert_allclose(v, g["vset"], rtol=1e-13)
+    np.testing.assert_allclose(w, g["wset"], rtol=1e-12)
+    np.testing.assert_allclose(s, g["sset"], rtol=1e-13)
+    twin = type("CylindersRadiallyIsotropic", (mcsas_amd.SASModel,), {"parameters": mcsas_amd.CylindersRadiallyIsotropic.parameters})()
+    for p_ours, p_twin in zip(m.params(), twin.params()):
+        p_twin.setValue(p_ours())
+        if hasattr(p_ours, "setActive"):
+            p_twin.setActive(p_ours.isActive()); p_twin.setActiveRange(p_ours.activeRange())
+    assert not hasattr(twin, "hipSource")
+    assert mcsas_amd.setup_from_model(twin).model_id == setup.model_id          # the same text, compiled once
+
+
 def test_bgfit_vs_reference():
     g = load("g3_bgfit.npz")
     I, sig = g["I"], g["sigma"]
@@ -70,7 +94,10 @@ TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q5
         "g14_sphere_q512_long.npz", "g14_sphere_q512_converge.npz",
         # round 4: chains the reference ENDS BY CONVERGENCE (criterion 1) for models with an orientation integral (cylinders 6228
         # steps, core-shell ellipsoids 1887 steps; 100 q x 200 contributions) and with positiveBackground (sphere, criterion 2, 5768 steps)
-        "g17_cyl_q100_converge.npz", "g17_ellcs_q100_converge.npz", "g17_sphere_q100_posbg_converge.npz"]
+        "g17_cyl_q100_converge.npz", "g17_ellcs_q100_converge.npz", "g17_sphere_q100_posbg_converge.npz",
+        # round 4: radially isotropic cylinders — no built-in kernel, the shipped model class hands its form factor to the library
+        # as HIP text (mcsas_amd.CylindersRadiallyIsotropic.hipSource, rows with an integral): every mode compiled at run time
+        "g18_cylradiso_q40.npz"]
 
 
 @pytest.mark.parametrize("name", TRAJ)
