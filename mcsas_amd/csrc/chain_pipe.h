@@ -8,7 +8,10 @@
 //       and — fp64 MFMA, v_mfma_f64_16x16x4_f64 — the sub-window's Gram block G[a][k] = Σ_q w d_a d_k, which does
 //       not depend on ft either.  Rows without an integral: the sub-window's d rows stay in LDS for the MFMAs, no
 //       `new` row is stored and a contribution's cached row is evaluated again when it has gone stale (lazy rows);
-//       rows with an integral: `new` row into a spare HBM row slot, slots swapped on acceptance.
+//       Rows with an integral (or a smeared model) — the kernel instantiation pipe_tick_kernel<M, QPL, true>: the producer waves
+//       of a chain PULL the window's rows from a queue, most expensive first, blocks whose queue is empty join other chains'
+//       (pipe_prod_rowq); `new` row into a spare HBM row slot, slots swapped on acceptance; the Gram blocks (8 steps) are taken by
+//       the scan block from the rows it has in LDS.
 //   scan blocks (one per chain) do SCAN(t): per sub-window ONE pass over its d rows gives h_k = Σ (w ft) d_k for
 //       the ft the sub-window starts from (eight waves, rows streamed HBM/L2 -> registers); then ONE wave takes
 //       the W decisions with lane g = step g: a candidate's fit sums are SC + a, SIC + e, SCC + 2h + g, and after
@@ -18,7 +21,8 @@
 // PROD(t+1) and SCAN(t) run concurrently inside one launch because a window's rows depend only on the random
 // stream and on row slots settled two windows earlier (2*Kb <= N), never on the decisions of the window
 // before.  Launch t+1 follows launch t on the same stream: the kernel boundary is the only synchronisation
-// between workgroups; there are no in-kernel spin waits and no cross-workgroup flags.
+// between workgroups; there are no in-kernel spin waits and no cross-workgroup flags (the row queue's counters are
+// fetch-and-add tickets: nobody waits on them).
 //
 // Chain schedule: an attempt (one mcFit call) is initialised at tick t_init (PROD evaluates the N
 // rows of the initial set, SCAN sums them and fits), then tick t > t_init handles window
