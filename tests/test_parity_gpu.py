@@ -1443,6 +1443,25 @@ def test_rows_with_an_integral_retries_and_uneven_chain_ends_follow_the_oracle(t
         np.testing.assert_array_equal(getattr(out[engine.EXEC_PIPELINE], name), getattr(out[engine.EXEC_WAVE], name), err_msg=name)
 
 
+def test_row_queue_window_at_its_cap_of_512_steps():
+    """Rows with an integral, more than 1024 contributions: the window is capped at one proposal per thread of a workgroup (512
+    steps, 64 sub-windows) — core-shell ellipsoids, 1100 contributions, three chains over 1300 steps (two full windows and a part of
+    a third, a sweep over the contributions and a fifth) give the wavefront mode's arrays."""
+    q, I, sig = _synthetic(64)
+    lo, hi = RANDOM_RANGES["ellcs"]
+    m, _ = make_models("ellcs", lo, hi, intDiv=12.)
+    out = {}
+    for mode in (engine.EXEC_PIPELINE, engine.EXEC_WAVE):
+        st = engine.Settings(n_contrib=1100, n_reps=3, max_iter=1300, conv_crit=1e-9, max_retries=0, seed=5, exec_mode=mode)
+        plan = engine.Plan(m.setup(), q, I, sig, st)
+        if mode == engine.EXEC_PIPELINE:
+            assert plan.info["exec_mode"] == "pipeline" and plan.info["window"] == 512
+        plan.launch(); out[mode] = plan.fetch(); plan.close()
+    for name in ("contribs", "num_iter", "num_moves", "draws"):
+        np.testing.assert_array_equal(getattr(out[engine.EXEC_PIPELINE], name), getattr(out[engine.EXEC_WAVE], name), err_msg=name)
+    assert out[engine.EXEC_PIPELINE].num_moves.min() > 20
+
+
 def test_plugin_model_with_an_integral_runs_the_row_queue_kernels():
     """A plug-in that declares `#define MCSAS_PLUGIN_ROW_CLASS 1` (its form factor loops over orientations: isotropic ellipsoids,
     models/ellipsoidsisotropic.py:51-81, written the plain way) is spread over the chip like the built-in models with an
