@@ -632,6 +632,29 @@ def test_stop_word_is_honoured_in_every_mode(mode):
     assert (res.num_iter < 10**6).all()               # left at the first poll, not after the budget
 
 
+@pytest.mark.parametrize("mode", [engine.EXEC_PIPELINE, engine.EXEC_WAVE])
+def test_stop_word_set_while_chains_with_an_integral_are_running(mode):
+    """McSAS.stop (mcsas.py:357) raised from another thread 30 ms into a run of cylinder chains with a budget of 1e6 steps (a few
+    seconds of work at most, so a stop that is not seen still ends): the row-queue pipeline forwards the word with the next ticks,
+    the wavefront kernel reads it through its relay — every chain leaves early, not converged, without another attempt."""
+    import ctypes, threading, time
+    q, I, sig = _synthetic(128)
+    m, _ = make_models("cyl_aspect", *RANDOM_RANGES["cyl_aspect"], intDiv=20.)
+    budget = 10**6
+    warm = engine.Settings(n_contrib=64, n_reps=6, max_iter=64, conv_crit=0.0, max_retries=0, seed=3, exec_mode=mode)
+    engine.analyse(m.setup(), q, I, sig, warm)                # (library, plan memory and kernels warm: the timer below is about the run)
+    stop = ctypes.c_int32(0)
+    st = engine.Settings(n_contrib=64, n_reps=6, max_iter=budget, conv_crit=0.0, max_retries=2, seed=3, exec_mode=mode)
+    timer = threading.Timer(0.03, lambda: setattr(stop, "value", 1))
+    t0 = time.perf_counter()
+    timer.start()
+    res = engine.analyse(m.setup(), q, I, sig, st, stop=stop)
+    wall = time.perf_counter() - t0
+    timer.cancel()
+    assert (res.num_iter < budget).all() and (res.num_iter > 0).all(), (res.num_iter, wall)
+    assert (res.converged == 0).all() and (res.attempts == 1).all()          # (stopped: no retry, mcsas.py:240-245)
+
+
 def test_many_reps_in_pipeline_and_replay_overflow_reporting():
     g = load("g4_sphere_q100_fixed.npz")
     m, _ = make_models("sphere", g["spec_lo"], g["spec_hi"])
