@@ -733,11 +733,13 @@ def gen_big_trajectories():
     save_traj("g9_kho_q64.npz", data_vectors(d), spec, run_mcfit(algo, n, 3006))
 
 
-def gen_kholodenko_config5(steps=300):
+def gen_kholodenko_config5(steps=300, fname="g9_kho_q512.npz"):
     """BASELINE config 5 AS NAMED: the Kholodenko fit on testdata/sasfit_kho-1-10-1000.dat at 512 q x
     600 contributions.  The file has 501 rows; the 512-point grid is the loader's (q, I) interpolated
     log-log onto logspace(q_min, q_max, 512) with sigma = 1 % I.  QUADPACK makes this slow
-    (~0.8 ms per q per form factor: ~4 min for the initial set, ~0.8 s per step)."""
+    (~0.8 ms per q per form factor: ~4 min for the initial set, ~0.8 s per step).  Round 5: `kho5_long` stores the same
+    chain (same seed, same stream: its first 300 steps ARE g9_kho_q512) over 1300 steps = more than two sweeps over the 600
+    contributions, so that every contribution is proposed again after it may have been replaced (g9_kho_q512_long.npz)."""
     d0 = kholodenko_file_data(0)
     q0 = np.array(d0.x0.unit.toDisplay(d0.q) if hasattr(d0.x0.unit, "toDisplay") else d0.q * 1e-9, dtype=float)
     I0 = np.array(d0.f.binnedData, dtype=float)
@@ -757,7 +759,7 @@ def gen_kholodenko_config5(steps=300):
                 lo=[min(p.activeRange()) for p in mk.activeParams()],
                 hi=[max(p.activeRange()) for p in mk.activeParams()], gen=[1, 0, 0],
                 comp_exp=0.6666666, max_iter=steps, conv_crit=1e-9)
-    save_traj("g9_kho_q512.npz", data_vectors(d), spec, run_mcfit(algo, n, 3005),
+    save_traj(fname, data_vectors(d), spec, run_mcfit(algo, n, 3005),
               extra=dict(file_q_nm=q0, file_I=I0))
 
 
@@ -974,13 +976,21 @@ def gen_free_running_heavy(which=("cyl", "ellcs", "kho")):
             out = _free_run(m, d, hists, 200, 8, 1.0, 1601 if tag == "cyl" else 1602)
             out["truth"] = truth
         else:
-            d = kholodenko_file_data(64)
+            # "kho": 64 bins x 64 contributions x 3 repetitions to criterion 12 (round 4); "kho32" (round 5): 32 bins x 48
+            # contributions x 12 repetitions to criterion 8 — a pilot with the numpy oracle reaches 9.3 / 6.3 after 1500 steps,
+            # 5.0 / 4.5 after 4000 — so that the comparison has twelve reference repetitions behind its standard errors
+            big = tag == "kho"
+            d = kholodenko_file_data(64 if big else 32)
             m = Kholodenko()
             ap = m.activeParams()
             spec = dict(model="kholodenko", lo=[min(p.activeRange()) for p in ap], hi=[max(p.activeRange()) for p in ap],
                         gen=[1, 0, 0], comp_exp=0.6666666)
             hists = [(p.name(), min(p.activeRange()), max(p.activeRange()), 8, "log" if i == 0 else "lin", "vol") for i, p in enumerate(ap)]
-            out = _free_run(m, d, hists, 64, 3, float(os.environ.get("G16_KHO_CRIT", "12.0")), 1603, max_iter=20000)
+            if big:
+                out = _free_run(m, d, hists, 64, 3, float(os.environ.get("G16_KHO_CRIT", "12.0")), 1603, max_iter=20000)
+            else:
+                out = _free_run(m, d, hists, 48, int(os.environ.get("G16_KHO32_REPS", "12")),
+                                float(os.environ.get("G16_KHO32_CRIT", "8.0")), 1604, max_iter=20000)
         out.update({"data_" + k: v for k, v in data_vectors(d).items()})
         out.update({"spec_" + k: np.array(v) for k, v in spec.items()})
         np.savez_compressed(os.path.join(OUT, "g16_%s_free.npz" % tag), **out)
@@ -1094,6 +1104,8 @@ if __name__ == "__main__":
         gen_param_declarations()
     if "kho5" in which:
         gen_kholodenko_config5()
+    if "kho5_long" in which:                                   # round 5: two sweeps (~25 min of QUADPACK)
+        gen_kholodenko_config5(steps=1300, fname="g9_kho_q512_long.npz")
     if "series" in which:
         gen_series()
     if "quickstart" in which or not sys.argv[1:]:
@@ -1105,6 +1117,8 @@ if __name__ == "__main__":
         gen_free_running_heavy(("cyl", "ellcs"))
     if "free_kho" in which:
         gen_free_running_heavy(("kho",))
+    if "free_kho32" in which:                                  # round 5: ~30 min of QUADPACK
+        gen_free_running_heavy(("kho32",))
     if "converge" in which or not sys.argv[1:]:
         gen_converging_trajectories()
     if "converge_posbg" in which:
