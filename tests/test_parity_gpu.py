@@ -1398,6 +1398,55 @@ def test_bench_workload_at_full_budget_equals_the_c_oracle_chain_by_chain():
     assert 900 < res.num_moves.mean() < 1600            # (~6 % of the steps are accepted)
 
 
+@pytest.mark.parametrize("config,tag,lo,hi,steps", [
+    (3, "cyl_aspect", [1e-9, 0.5], [1e-7, 20.0], 4000),
+    (4, "ellcs", [1e-9, 2e-9, 2e-10], [1e-7, 2e-7, 1e-8], 3000)])
+def test_bench_workloads_of_configs_3_and_4_equal_the_c_oracle_chain_by_chain(config, tag, lo, hi, steps):
+    """BASELINE configs 3 and 4 AS bench.py TIMES THEM — its ground-truth curve of the model under test (512 q / 1024 q), 400 / 1000
+    contributions, the per-GPU share of the repetitions (25 / 50), row-queue pipeline with helping blocks, Philox streams — over ten
+    sweeps (4000 steps) / three sweeps (3000 steps) against the plain-C oracle (oracle/c: models/cylindersisotropic.py:50-101,
+    ellipsoidalcoreshell.py:59-97 restated with libm and Cephes' J1, pinned on the CPU against the reference's own chains) on the
+    same counter-based streams: every chain takes the same decisions (move counts and parameter sets exact, chi-squared 1e-7)."""
+    from oracle import c_oracle
+    import bench
+    wl = bench.workload(config, 0)
+    _, spec = make_models(tag, lo, hi)
+    setup = wl["model"].setup()
+    assert list(setup.gen_lo) == list(spec.lo) and list(setup.gen_hi) == list(spec.hi) and tuple(setup.gen_kind) == tuple(spec.gen)
+    np.testing.assert_array_equal(setup.params, spec.values)
+    st = engine.Settings(n_contrib=wl["n"], n_reps=wl["reps_gpu"], max_iter=steps, conv_crit=0.0, max_retries=0, seed=1000,
+                         exec_mode=engine.EXEC_PIPELINE)
+    plan = engine.Plan(setup, wl["q"], wl["I"], wl["sigma"], st)
+    assert plan.info["exec_mode"] == "pipeline"
+    plan.launch(); res = plan.fetch(); plan.close()
+    ref = c_oracle.analyse(spec, wl["q"], wl["I"], wl["sigma"], wl["n"], wl["reps_gpu"], steps, 0.0, seed=1000,
+                           threads=min(16, os.cpu_count() or 1))
+    assert (res.num_iter == steps).all() and (ref.num_iter == steps).all()
+    np.testing.assert_array_equal(res.num_moves, ref.num_moves)
+    np.testing.assert_allclose(res.contribs, ref.contribs, rtol=1e-12)
+    np.testing.assert_allclose(res.chisq, ref.chisq, rtol=1e-7)
+    assert res.num_moves.min() > 50
+
+
+def test_many_chains_as_timed_sampled_against_the_c_oracle():
+    """The kernel north_star describes, at the size bench.py's `many_chains` times it — 8192 chains x 20 000 steps, one wavefront per
+    chain (chain_wave_kernel<0, 8, true>) — with 32 of the chains (four blocks of eight, first / middle / last) against the plain-C
+    oracle on the same Philox streams (chain id = repetition index): same move counts, parameter sets, chi-squared."""
+    from oracle import c_oracle
+    q, I, sig = _synthetic(512)
+    lo, hi = np.pi / q.max(), np.pi / q.min()
+    m, _ = make_models("sphere", [lo], [hi])
+    st = engine.Settings(n_contrib=400, n_reps=8192, max_iter=20000, conv_crit=0.0, max_retries=0, seed=20250101, exec_mode=engine.EXEC_WAVE)
+    res = engine.analyse(m.setup(), q, I, sig, st)
+    assert (res.num_iter == 20000).all()
+    for first in (0, 2731, 5000, 8184):
+        ref = c_oracle.analyse_sphere(q, I, sig, lo, hi, 400, 8, 20000, 0.0, seed=20250101, rep_offset=first, threads=8)
+        sl = slice(first, first + 8)
+        np.testing.assert_array_equal(res.num_moves[sl], ref.num_moves)
+        np.testing.assert_allclose(res.contribs[:, :, sl], ref.contribs, rtol=1e-12)
+        np.testing.assert_allclose(res.chisq[sl], ref.chisq, rtol=1e-7)
+
+
 @pytest.mark.parametrize("tag", ["cyl_aspect", "kholodenko", "ellcs"])
 def test_rows_with_an_integral_give_the_same_chain_whatever_the_chain_count(tag):
     """Pipeline mode, rows that cost an integral: the producer blocks per chain follow the number of chains in the launch, and which
