@@ -31,6 +31,13 @@ resource the counters name for these kernels: fp64 vector issue), `launch_ms` (m
 (configs 3-5 at their per-GPU repetition counts, each sustained over >= 1 s of back-to-back launches),
 `convergence_run` (criterion 1 as BASELINE names it), `quickstart` (the reference's published workload end to end) and
 `cpu_baseline`.
+
+Round 5: BASELINE names configs 3-5 as TOTALS over 8 GPUs (200 / 400 / 100 repetitions).  With the default --config 2 every run
+— one rank or N — also runs those totals strong-sharded over the ranks (`shard_reps`, chain id = global repetition index, no
+collective on the data path, all-reduce of the timings only): `configs[k].strong_total` in the N = 1 line (all repetitions on
+one GPU), `configs[k]` in an N > 1 line, so that a 1 -> N ratio exists for each.  Per config 2-4 the line also carries
+`cpu_baseline` (the C oracle timed on the same workload shape) and `chisq_rel_diff_vs_cpu`: the final chi² of chains run on the GPU
+and by the C oracle on identical Philox streams (max over chains of the relative difference).
 """
 import argparse
 import json
@@ -174,6 +181,40 @@ def cpu_baseline(q, I, sigma, lo, hi, seconds_target=12.0):
     out["numpy_port"] = {"value": float(sum(done)) / dtn, "cores": threads,
                          "sample": "%d processes x %d MC steps (incl. init), oracle/mcsas_oracle.py" % (threads, nsteps)}
     return out
+
+
+def oracle_spec(setup):
+    """The checker's description (oracle.mcsas_oracle.ModelSpec) of a flattened product model (engine.ModelSetup)."""
+    from oracle import mcsas_oracle as O
+    return O.ModelSpec(int(setup.model_id), tuple(int(i) for i in setup.active_index), np.array(setup.gen_lo, float),
+                       np.array(setup.gen_hi, float), tuple(int(k) for k in setup.gen_kind), np.array(setup.params, float))
+
+
+def cpu_vs_gpu_chains(wl, steps, dev_index, seed=1):
+    """BASELINE.md §3, per config: `threads` chains of the workload run (a) on the GPU through the C ABI and (b) by the plain-C
+    oracle (oracle/c) on the SAME counter-based random streams for `steps` steps each — the oracle's wall time is the CPU baseline
+    of this config (one chain per thread), the chains' final chi² are compared (max over chains of |gpu - cpu| / cpu), and so are
+    their move counts.  Only the checker is timed here; the GPU side is untimed."""
+    from oracle import c_oracle
+    from mcsas_amd import engine
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(avail, int(os.environ.get("MCSAS_BENCH_CPU_THREADS", "16"))))
+    setup = wl["model"].setup()
+    st = engine.Settings(n_contrib=wl["n"], n_reps=threads, max_iter=steps, conv_crit=0.0, max_retries=0, seed=seed, device=dev_index)
+    res = engine.analyse(setup, wl["q"], wl["I"], wl["sigma"], st)
+    c_oracle.load()
+    t0 = time.time()
+    ref = c_oracle.analyse(oracle_spec(setup), wl["q"], wl["I"], wl["sigma"], wl["n"], threads, steps, 0.0, seed=seed, threads=threads)
+    dt = time.time() - t0
+    rel = np.abs(res.chisq - ref.chisq) / np.abs(ref.chisq)
+    return {"value": float(ref.num_iter.sum()) / dt, "unit": "MC steps/s", "cores": threads, "kind": "port",
+            "host_cores_total": os.cpu_count(), "host_cores_available": avail,
+            "sample": "%d chains x %d MC steps (incl. %d-contribution init each), %s, C oracle (oracle/c, gcc -O2, libm, Cephes J1), "
+                      "%d threads, %.1f s" % (threads, steps, wl["n"], wl["name"], threads, dt),
+            "chisq_rel_diff_vs_cpu": float(rel.max()), "chisq_rel_diff_target": 1e-5,
+            "moves_equal": bool(np.array_equal(res.num_moves, ref.num_moves)),
+            "chisq_gpu_median": float(np.median(res.chisq)), "chisq_cpu_median": float(np.median(ref.chisq)),
+            "compared": "%d chains, %d steps each, identical Philox streams (seed %d), GPU exec mode auto" % (threads, steps, seed)}
 
 
 def _numpy_chain(args):
@@ -458,6 +499,9 @@ def main():
                   "note": "config 2's 50 repetitions in all, sharded over the ranks: 6-7 chains per GPU, where an analysis is bound "
                           "by the per-tick latency of the pipeline (3.1 ms for 7 chains against 3.4 for 50 on one GPU), not by throughput"}
         pl2.close()
+    totals = None
+    if args.config == 2 and not args.no_configs and (not dry or os.environ.get("MCSAS_BENCH_DRY_CONFIGS") == "1"):
+        totals = named_totals(dev_index, world, rank, use_dist, backend, dry, barrier)
     ranks_seen = 1
     if use_dist:
         dev = "cuda" if backend == "nccl" and not dry else "cpu"
@@ -527,6 +571,7 @@ def main():
                 traffic = (pm["fetch_bytes_per_mc_step"] + pm["write_bytes_per_mc_step"]) * steps_per_launch / launch_s / 1e9
                 source = "from_profile: %s (commit %s)" % (tj, pm.get("commit", "?"))
             algorithmic = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                           "measured_in_this_run": True,
                            "note": "40*Q B per MC step (SURVEY 8d streaming model, no on-chip reuse credit) x MC steps per launch / mean "
                                    "HIP-event time of a launch; q, I, sigma and ft stay on chip, so this is not memory traffic"}
             ij, pvt = latest_profile("valu_per_step.json")
@@ -535,11 +580,11 @@ def main():
                 rate = pv["valu_wave_instr_per_mc_step"] * steps_per_launch / launch_s
                 out["roofline_valu"] = {"bound": "valu", "achieved": rate / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9,
                                         "unit": "G wave-instr/s", "frac": rate / FP64_VECTOR_PEAK_INSTR,
-                                        "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
+                                        "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"], "measured_in_this_run": False,
                                         "source": "from_profile: %s (SQ_INSTS_VALU pass, commit %s)" % (ij, pv.get("commit", "?")),
                                         "note": "fp64 vector issue: 1024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz; achieved = "
                                                 "SQ_INSTS_VALU per MC step (committed counter pass) x MC steps per launch / mean HIP-event time of a launch"}
-            out["roofline"] = dict(algorithmic, traffic=traffic, traffic_unit="GB/s", traffic_source=source)
+            out["roofline"] = dict(algorithmic, traffic=traffic, traffic_unit="GB/s", traffic_source=source, traffic_measured_in_this_run=False)
         # outside the timed region: the same repetitions run the way McSAS.analyse runs them — convergenceCriterion 1 (BASELINE),
         # maxIterations 1e5, one attempt — -> final chi² and how many got there, to be read against chisq_of_truth.
         if not dry and not args.no_convergence_run:
@@ -549,14 +594,86 @@ def main():
             out["quickstart"] = quickstart(dev_index)
         if not dry and not args.no_configs and world == 1 and args.config == 2:
             out["configs"] = other_configs(dev_index)
+            for k, e in (totals or {}).items():                  # the named totals on ONE GPU: the denominator of a 1 -> N ratio
+                out["configs"][k]["strong_total"] = e
+        elif totals:                                             # N > 1 (or the CPU dry run): configs 3-5 as named, whole node
+            out["configs"] = totals
         if not dry and not args.no_many_chains and not args.no_configs and world == 1 and args.config == 2:
             out["many_chains"] = many_chains(wl, dev_index)
         if not dry and not args.no_cpu_baseline and world == 1 and args.config == 2:   # the CPU baseline is timed at N = 1 only
             lo, hi = np.pi / q.max(), np.pi / q.min()
             out["cpu_baseline"] = cpu_baseline(q, I, sigma, lo, hi)
+            # BASELINE.md §3 per config: the C oracle timed on each workload's shape and the chains' final chi² GPU vs CPU on identical
+            # streams; the budgets are the ones tests/test_parity_gpu.py checks chain by chain (20 000 / 4000 / 3000 steps)
+            cmp2 = cpu_vs_gpu_chains(wl, 20000, dev_index)
+            out["cpu_baseline"].update({k: cmp2[k] for k in ("chisq_rel_diff_vs_cpu", "chisq_rel_diff_target", "moves_equal", "compared")})
+            out["chisq_rel_diff_vs_cpu"] = cmp2["chisq_rel_diff_vs_cpu"]
+            if "configs" in out and not args.no_configs:
+                for cfg, steps_c in ((3, 4000), (4, 3000)):
+                    e = cpu_vs_gpu_chains(workload(cfg, dev_index), steps_c, dev_index)
+                    out["configs"][str(cfg)]["cpu_baseline"] = e
+                    out["configs"][str(cfg)]["chisq_rel_diff_vs_cpu"] = e["chisq_rel_diff_vs_cpu"]
+                out["configs"]["5"]["cpu_baseline"] = None
+                out["configs"]["5"]["cpu_baseline_note"] = ("the C oracle restates the models of configs 2-4; the worm-like chain's checker is the "
+                                                            "numpy / QUADPACK restatement (1-2 rows per second): chain-by-chain parity of config 5 "
+                                                            "is tests/golden/g9_kho_q512*.npz, replayed by tests/test_parity_gpu.py")
         print(json.dumps(out))
     if use_dist:
         tdist.destroy_process_group()
+
+
+def named_totals(dev_index, world, rank, use_dist, backend, dry, barrier):
+    """BASELINE configs 3-5 AS NAMED: 200 / 400 / 100 repetitions in all, sharded over the ranks (mcsas.py:214 is the loop being
+    sharded; mcsas_amd.dist.shard_reps; chain id = global repetition index).  Every rank runs its block — one warm-up launch, then
+    `launches` timed ones between barriers — and the timings meet in two all-reduces (MAX of the time, SUM of the steps): whole-job
+    MC steps/s per config.  At world size 1 the same code runs all repetitions on the one GPU, which is the denominator of a 1 -> N
+    ratio.  Called on EVERY rank (collectives inside)."""
+    import torch
+    from mcsas_amd import engine, dist as mdist
+    out = {}
+    for cfg, budget, launches in ((3, 10000, 2), (4, 15000, 2), (5, 10000, 2)):
+        wl = workload(cfg, dev_index, dry)
+        total = wl["reps_total"]
+        first, reps = mdist.shard_reps(total, world, rank)
+        setup = wl["model"].setup()
+        steps, dt, info = 0, 0.0, {}
+        if dry:
+            plan = DryPlan(wl["n"], setup.n_active, len(wl["q"]), reps)
+            plan.reseed(1, first); plan.launch(); plan.fetch()
+            info = plan.info
+        elif reps > 0:
+            st = engine.Settings(n_contrib=wl["n"], n_reps=reps, max_iter=budget, conv_crit=0.0, max_retries=0, seed=20250101,
+                                 rep_offset=first, device=dev_index)
+            plan = engine.Plan(setup, wl["q"], wl["I"], wl["sigma"], st)
+            plan.reseed(600, first); plan.launch(); plan.fetch(want_arrays=False)
+        barrier()
+        t0 = time.perf_counter()
+        if not dry and reps > 0:
+            for i in range(launches):
+                plan.reseed(601 + i, first); plan.launch(slot=i & 1)
+                if i >= 1:
+                    plan.fetch(want_arrays=False, slot=(i - 1) & 1); steps += plan.total_steps
+            plan.fetch(want_arrays=False, slot=(launches - 1) & 1); steps += plan.total_steps
+            info = plan.info
+        barrier()
+        dt = time.perf_counter() - t0
+        if not dry and reps > 0:
+            plan.close()
+            engine.release_cached_memory()
+        ranks_seen, tot_steps, tmax = 1, float(steps), dt
+        if use_dist:
+            import torch.distributed as tdist
+            dev = "cuda" if backend == "nccl" and not dry else "cpu"
+            t = torch.tensor([dt, float(steps), 1.0], dtype=torch.float64, device=dev)
+            tm = t.clone(); tdist.all_reduce(tm, op=tdist.ReduceOp.MAX)
+            ts = t.clone(); tdist.all_reduce(ts, op=tdist.ReduceOp.SUM)
+            tmax, tot_steps, ranks_seen = float(tm[0]), float(ts[1]), int(round(float(ts[2])))
+        out[str(cfg)] = {"workload": "%s, %d reps IN ALL sharded over %d rank(s) (%d on rank 0), %d MC steps per chain per launch"
+                                     % (wl["name"], total, world, reps, budget),
+                         "value": None if dry else tot_steps / max(tmax, 1e-12), "unit": "MC steps/s", "scaling": "strong",
+                         "reps_total": total, "reps_rank0": reps, "ranks_seen": ranks_seen, "n_gpus": world, "launches": launches,
+                         "mc_steps": tot_steps, "timed_region_s": tmax, "exec_mode": info.get("exec_mode"), "window": info.get("window")}
+    return out
 
 
 def latest_profile(suffix):
@@ -765,15 +882,18 @@ def many_chains(wl, dev_index, reps=8192, mc_steps=20000, seconds=1.5):
          "launch_ms": {"min": float(np.min(ms)), "median": float(np.median(ms)), "max": float(np.max(ms))},
          "rate_of_fastest_launch": reps * mc_steps / (float(np.min(ms)) * 1e-3), "rate_of_slowest_launch": reps * mc_steps / (float(np.max(ms)) * 1e-3),
          "clocks": cs.summary(),
-         "roofline": {"bound": "hbm", "achieved": 40 * len(wl["q"]) * rate / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                      "frac": 40 * len(wl["q"]) * rate / HBM_PEAK}}
+         # the chain state of this kernel never leaves the chip (ft in registers, tables in LDS): SURVEY 8d's 40 Q bytes per step are an
+         # algorithmic figure that no memory system carries, so there is no `frac` against HBM; what bounds the kernel is fp64 issue
+         "algorithmic_gbps": 40 * len(wl["q"]) * rate / 1e9,
+         "algorithmic_note": "40*Q B per MC step x steps/s (SURVEY 8d streaming model); NOT memory traffic and not a roofline fraction"}
     ij, pvt = latest_profile("valu_per_step.json")
     pv = pvt.get("wave8192")
     if pv:
         r = pv["valu_wave_instr_per_mc_step"] * rate
-        e["roofline_valu"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
-                              "frac": r / FP64_VECTOR_PEAK_INSTR, "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
-                              "source": "from_profile: %s (commit %s)" % (ij, pv.get("commit", "?"))}
+        e["roofline"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
+                         "frac": r / FP64_VECTOR_PEAK_INSTR, "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
+                         "measured_in_this_run": False,
+                         "source": "from_profile: %s (SQ_INSTS_VALU pass, commit %s); rate measured in this run" % (ij, pv.get("commit", "?"))}
     return e
 
 
@@ -871,11 +991,13 @@ def other_configs(dev_index, seconds=1.0):
         pv = prof.get(str(cfg))
         tr = traf.get(str(cfg))
         traffic = (tr["fetch_bytes_per_mc_step"] + tr["write_bytes_per_mc_step"]) * rate_one / 1e9 if tr else None
-        e["roofline"] = dict(alg, traffic=traffic, traffic_unit="GB/s")
+        e["roofline"] = dict(alg, traffic=traffic, traffic_unit="GB/s", measured_in_this_run=True, traffic_measured_in_this_run=False,
+                             traffic_source="from_profile: %s" % tj if tr else None)
         if pv:
             r = pv["valu_wave_instr_per_mc_step"] * rate_one
             e["roofline_valu"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
                                   "frac": r / FP64_VECTOR_PEAK_INSTR, "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
+                                  "measured_in_this_run": False,
                                   "source": "from_profile: %s / %s (commit %s)" % (ij, tj, pv.get("commit", "?"))}
         out[str(cfg)] = e
     return out

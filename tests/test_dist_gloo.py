@@ -57,7 +57,7 @@ def test_single_process_is_a_passthrough():
     np.testing.assert_array_equal(out["a"], np.arange(6.0).reshape(3, 2))
 
 
-def _run_bench(tmp_path, gpus, extra, tag):
+def _run_bench(tmp_path, gpus, extra, tag, env_extra=None):
     """bench.py's own multi-rank code path on CPU: MCSAS_BENCH_DRY=1 swaps the GPU plan for a payload that
     depends only on (seed, global repetition index); gloo carries the all-gather.  --gpus N with no launcher
     around makes bench.py start its N ranks itself."""
@@ -67,6 +67,7 @@ def _run_bench(tmp_path, gpus, extra, tag):
     env = dict(os.environ, MCSAS_BENCH_DRY="1", MCSAS_BENCH_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    env.update(env_extra or {})
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
            "--dump", dump] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -111,6 +112,20 @@ def test_bench_default_scaling_follows_the_config(tmp_path):
     assert two["scaling"] == "weak" and two["config"]["reps_total"] == 100 and two["config"]["reps_per_gpu"] == 50
     five, _ = _run_bench(tmp_path, 2, ["--config", "5"], "c5")
     assert five["scaling"] == "strong" and five["config"]["reps_total"] == 100 and five["config"]["reps_per_gpu"] == 50
+
+
+def test_bench_runs_the_named_totals_of_configs_3_to_5_over_the_ranks(tmp_path):
+    """`bench.py --gpus N` with the default --config 2 also runs BASELINE's configs 3-5 as they are named — 200 / 400 / 100
+    repetitions IN ALL, sharded over the ranks (mcsas.py:214 is the loop being sharded) — and reports them per config with the ranks
+    it saw; the N = 1 line carries the same totals on one rank (the denominator of a 1 -> N ratio).  Dry run: no measurement."""
+    one, _ = _run_bench(tmp_path, 1, [], "t1", {"MCSAS_BENCH_DRY_CONFIGS": "1"})
+    two, _ = _run_bench(tmp_path, 2, [], "t2", {"MCSAS_BENCH_DRY_CONFIGS": "1"})
+    for k, total in (("3", 200), ("4", 400), ("5", 100)):
+        a, b = one["configs"][k], two["configs"][k]
+        assert a["reps_total"] == b["reps_total"] == total and a["scaling"] == b["scaling"] == "strong"
+        assert a["ranks_seen"] == 1 and a["reps_rank0"] == total
+        assert b["ranks_seen"] == 2 and b["reps_rank0"] == total // 2 and b["n_gpus"] == 2
+        assert a["value"] is None and b["value"] is None               # dry run: never a measurement
 
 
 def test_bench_refuses_a_world_size_it_was_not_asked_for(tmp_path):

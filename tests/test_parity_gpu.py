@@ -409,6 +409,31 @@ def test_mcsas_front_end_takes_a_device_list():
 
 
 
+def test_mcsas_front_end_device_list_with_an_integral_model_in_auto_mode():
+    """mcsas_amd.McSAS(device=[0, 0]) for a model whose rows cost an integral, MCSAS_EXEC_AUTO (it picks the row-queue pipeline on
+    every block): the repetition loop of mcsas.py:214-262 split over two plans on two host threads inside the C ABI gives the arrays of
+    one device bit for bit (window fixed by the contribution count, chain id = global repetition index), histogram included."""
+    g = load("g16_cyl_free.npz")
+    out = []
+    for dev in (0, [0, 0]):
+        m, _ = make_models("cyl_aspect", g["spec_lo"], g["spec_hi"], [int(x) for x in g["spec_gen"]], sld=float(g["spec_sld"]),
+                           intDiv=float(g["spec_int_div"]))
+        m.radius.histograms().append(mcsas_amd.Histogram(m.radius, float(g["spec_lo"][0]), float(g["spec_hi"][0]), binCount=12,
+                                                         xscale='log', yweight='vol'))
+        algo = mcsas_amd.McSAS(seed=5, device=dev)
+        algo.numContribs.setValue(96); algo.numReps.setValue(7); algo.convergenceCriterion.setValue(3.0)
+        algo.maxIterations.setValue(4000)
+        algo.model = m
+        algo.data = mcsas_amd.SASData(g["data_q"], g["data_I"], g["data_sigma"], f_limit=g["data_f_limit"])
+        algo.calc()
+        assert algo.result, "calc() gave no result"
+        out.append((algo.result[0]["contribs"].copy(), np.asarray(algo.result[0]["fitMeasValMean"]).copy(),
+                    np.asarray(m.radius.histograms()[0].bins.mean).copy(), algo.details.num_iter.copy()))
+    assert len(set(out[0][3].tolist())) > 2                    # (chains end at different steps)
+    for a, b in zip(out[0], out[1]):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("waves", [1, 8, 5, -3])
 def test_free_running_philox_matches_oracle(waves):
     """Free-running chains (device Philox) follow the oracle run with the same counter-based stream:
