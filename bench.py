@@ -592,6 +592,7 @@ def main():
         if not dry and not args.no_convergence_run and world == 1 and args.config == 2:
             out["calc_breakdown"] = calc_breakdown(wl, dev_index)
             out["quickstart"] = quickstart(dev_index)
+            out["python_only_model"] = python_only_model(wl, dev_index)
         if not dry and not args.no_configs and world == 1 and args.config == 2:
             out["configs"] = other_configs(dev_index)
             for k, e in (totals or {}).items():                  # the named totals on ONE GPU: the denominator of a 1 -> N ratio
@@ -1001,6 +1002,55 @@ def other_configs(dev_index, seconds=1.0):
                                   "source": "from_profile: %s / %s (commit %s)" % (ij, tj, pv.get("commit", "?"))}
         out[str(cfg)] = e
     return out
+
+
+def python_only_model(wl, dev_index, chains=16, steps=2000, window=64):
+    """A ScatteringModel that exists only as Python (the reference's plug-in contract: numpy formfactor / volume, no kernel id, no HIP
+    text) on config 2's data: the library draws the proposals and calls back into the model's calcIntensity for the rows of a window
+    of steps, the device does the rest (mcsas_hip_analyse_host_rows).  Host-bound by construction: the rate is what the model's own
+    Python costs per row (the reference: the same row evaluation TWICE per step plus a MINPACK fit, 2.3-2.9e3 steps/s per core)."""
+    import mcsas_amd
+    from mcsas_amd import engine
+    from mcsas_amd.scatteringmodels import host_model_calc
+
+    class PythonOnlySphere(mcsas_amd.SASModel):
+        shortName = "Sphere (Python only)"
+        parameters = mcsas_amd.Sphere.parameters
+
+        def __init__(self):
+            super().__init__()
+            self.radius.setActive(True)
+
+        def volume(self):
+            return (np.pi * 4. / 3.) * self.radius()**3
+
+        def absVolume(self):
+            return self.volume() * self.sld()**2
+
+        def formfactor(self, dataset):
+            qr = self.getQ(dataset) * self.radius()
+            return 3. * (np.sin(qr) - qr * np.cos(qr)) / (qr**3.)
+
+    q = wl["q"]
+    m = PythonOnlySphere(); m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
+    data = mcsas_amd.SASData(q, wl["I"], wl["sigma"])
+    st = engine.Settings(n_contrib=wl["n"], n_reps=chains, max_iter=steps, conv_crit=0.0, max_retries=0, seed=20250101, device=dev_index)
+    spent = [0.0, 0]
+
+    def rows(pset):
+        t0 = time.perf_counter()
+        out = host_model_calc(m, data, pset, st.comp_exp, want_rows=True)[4]
+        spent[0] += time.perf_counter() - t0; spent[1] += len(pset)
+        return out
+    t0 = time.perf_counter()
+    res = engine.analyse_host_rows(m.setup(data), q, wl["I"], wl["sigma"], st, rows, window=window)
+    dt = time.perf_counter() - t0
+    return {"workload": "Sphere typed as a Python-only model (numpy formfactor / volume), config 2's data: %d q x %d contribs, %d reps x %d "
+                        "steps, window %d" % (len(q), wl["n"], chains, steps, window),
+            "value": float(res.num_iter.sum()) / dt, "unit": "MC steps/s", "wall_s": dt, "rows_evaluated": spent[1],
+            "callback_share": spent[0] / dt, "python_us_per_row": spent[0] / max(spent[1], 1) * 1e6,
+            "final_chisq_median": float(np.median(res.chisq)),
+            "note": "host-bound: the device waits for the model's own Python; everything but the rows (row cache, fit, chi², decisions) is on the GPU"}
 
 
 def quickstart(dev_index):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MCSAS_ABI_VERSION 3
+#define MCSAS_ABI_VERSION 4
 #define MCSAS_MAX_ACTIVE 4   /* active (fitted) parameters per contribution: columns of rset */
 #define MCSAS_MAX_PARAMS 8   /* full parameter vector of a model */
 #define MCSAS_MAX_DEVICES 16 /* devices one mcsas_hip_analyse call may spread its repetitions over */
@@ -77,7 +77,8 @@ enum {
     MCSAS_ENODEV = -2,      /* no usable HIP device */
     MCSAS_EHIP = -3,        /* HIP runtime error (see mcsas_hip_last_error) */
     MCSAS_ENOMEM = -4,
-    MCSAS_ESTREAM = -5      /* replay stream shorter than the draws a chain consumed */
+    MCSAS_ESTREAM = -5,     /* replay stream shorter than the draws a chain consumed */
+    MCSAS_ECALLBACK = -6    /* the caller's rows callback reported a failure (mcsas_hip_analyse_host_rows) */
 };
 
 /* Everything McSAS.analyse() reads from self.data, self.model and the algorithm settings. */
@@ -185,6 +186,28 @@ int mcsas_hip_analyse(const mcsas_problem *problem, mcsas_result *result);
 /* how mcsas_hip_analyse splits n_reps repetitions over n_devices devices: block `index` = repetitions
  * [*first, *first + *count) (contiguous, in device-list order, sizes differ by at most one; count may be 0) */
 int mcsas_hip_shard(int32_t n_reps, int32_t n_devices, int32_t index, int32_t *first, int32_t *count);
+
+/* ---- McSAS.analyse() for a model that exists only as HOST code (ABI 4) -------------------------------------------------
+ * The reference's plug-in contract is a ScatteringModel subclass with Python formfactor() / volume() / absVolume() / surface()
+ * (bases/model/scatteringmodel.py:16-58), evaluated one parameter set at a time by ScatteringModel.calc (:79-105: p.setValue(v)
+ * on every active parameter — which clips into the valueRange —, then calcIntensity, bases/model/sasmodel.py:46-79), found by
+ * FindModels in any file under models/ (utils/findmodels.py:120-186).  Such a model has no device code.  A proposal depends on the random
+ * stream only, never on the state of its chain (mcsas.py:358), so the library draws the proposals of the next `window` steps of
+ * every chain on the host (the same counter-based / replayed streams and generator transforms as every other entry point), hands
+ * ALL of them to `rows_cb` in one call, and runs everything else of McSAS.mcFit on the device (csrc/chain_feed.h): the row
+ * cache (`old`, mcsas.py:362), test = ft - old + new, the scale / background fit and chi² (:376), the decisions (:379-390), the
+ * final fit (:424-430); the retry loop of analyse() (:220-246) and McSAS.stop are followed between windows.
+ *   rows_cb(user, n, pset, rows): pset[n][n_active] parameter sets (activeParams() order, NOT yet clipped: setValue does that)
+ *     -> rows[n][nq] = calcIntensity(data, compensationExponent)[0] of each; return 0, anything else aborts with MCSAS_ECALLBACK.
+ *     Called from the calling thread only, with 1 <= n <= max(n_contrib, window) * n_reps rows (bounded by ~256 MB of rows).
+ *   window: proposals evaluated ahead per chain and call (< 1: 64); a chain that ends inside a window wastes the rest of it.
+ * Uses problem->{nq, q, intensity, sigma, n_active, gen_*, start_value, n_contrib, n_reps, max_iter, conv_crit, max_retries,
+ * find_background, positive_background, start_from_minimum, seed, rep_offset, replay_*, stop, device}; model_id, params, clip_*,
+ * comp_exp and smear_* are the callback's business (calcIntensity smears by itself, sasmodel.py:56-73).  nq <= 16384.
+ * result: as mcsas_hip_analyse; seconds[] = host wall time from the start of the call to the end of the repetition. */
+typedef int (*mcsas_rows_callback)(void *user, int32_t n, const double *pset, double *rows);
+int mcsas_hip_analyse_host_rows(const mcsas_problem *problem, mcsas_rows_callback rows_cb, void *user, int32_t window,
+                                mcsas_result *result);
 
 /* ---- resident plan: same work split so that inputs/workspaces live in HBM across runs ------- */
 typedef struct mcsas_plan mcsas_plan;

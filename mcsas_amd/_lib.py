@@ -13,7 +13,7 @@ import numpy as np
 
 MAX_ACTIVE = 4
 MAX_PARAMS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_DEVICES = 16
 
 # MCSAS_HIP_LIB selects another build of the SAME library (e.g. the -DMCSAS_STAMPS diagnostic build)
@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("MCSAS_HIP_LIB") or os.path.join(os.path.dirname(os.pa
 
 # every symbol include/mcsas_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = (
-    "mcsas_hip_analyse", "mcsas_hip_shard", "mcsas_hip_plan_create", "mcsas_hip_plan_launch", "mcsas_hip_plan_fetch",
+    "mcsas_hip_analyse", "mcsas_hip_analyse_host_rows", "mcsas_hip_shard", "mcsas_hip_plan_create", "mcsas_hip_plan_launch", "mcsas_hip_plan_fetch",
     "mcsas_hip_plan_launch_slot", "mcsas_hip_plan_fetch_slot",
     "mcsas_hip_plan_last_ms", "mcsas_hip_plan_total_steps", "mcsas_hip_plan_reseed", "mcsas_hip_plan_info",
     "mcsas_hip_plan_destroy", "mcsas_hip_model_calc", "mcsas_hip_bgfit", "mcsas_hip_observability",
@@ -33,6 +33,10 @@ SYMBOLS = (
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
+
+
+# mcsas_rows_callback (include/mcsas_hip.h): int cb(void *user, int32_t n, const double *pset, double *rows)
+RowsCallback = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, _dp, _dp)
 
 
 class HistogramSpec(C.Structure):
@@ -114,6 +118,7 @@ def load(tuning=False):
     lib.mcsas_hip_last_error.restype = C.c_char_p
     lib.mcsas_hip_device_count.restype = C.c_int
     lib.mcsas_hip_analyse.argtypes = [C.POINTER(Problem), C.POINTER(Result)]
+    lib.mcsas_hip_analyse_host_rows.argtypes = [C.POINTER(Problem), RowsCallback, C.c_void_p, C.c_int32, C.POINTER(Result)]
     lib.mcsas_hip_shard.argtypes = [C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p]
     lib.mcsas_hip_plan_create.argtypes = [C.POINTER(Problem), C.POINTER(C.c_void_p)]
     lib.mcsas_hip_plan_launch.argtypes = [C.c_void_p, C.c_void_p]

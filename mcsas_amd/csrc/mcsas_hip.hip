@@ -19,6 +19,7 @@
 #include "../../include/mcsas_hip.h"
 #include "chain_common.h"
 #include "small_kernels.h"   // model_rows_kernel, observability_kernel, hist_rows_kernel
+#include "chain_feed.h"     // feed_rows_kernel: chains whose rows the caller evaluates (mcsas_hip_analyse_host_rows)
 #include "chain_wg.h"   // WgGeom / wg_geometry only; the kernels are instantiated in kern_*.hip
 #include "chain_pipe.h" // PipeArgs / pipe_geometry only
 #include "chain_wide.h" // WIDE_* constants only
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(64) void hist_bins_kernel(int N, int P, int R, cons
     __syncthreads();
     if (lane == 32 || lane == 33) {
         const double tot = mom[0], m1 = mom[1], sg = mom[3];
-        const bool any = mom[4] != 0., ok3 = any && (tot * sg) != 0. && isfinite(tot * sg);
+        const bool any = mom[4] != 0., ok3 = any && (tot * sg) != 0.;      // (utils/parameter.py:106-107: only an exact zero is skipped; NaN goes on)
         const double sg2 = sg * sg;
         double acc = 0.;
         for (int c = 0; c < N; ++c) {
@@ -996,8 +997,25 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         else if (waves > 1) mode = MCSAS_EXEC_WORKGROUP;
         else {
             PipeGeom pg; WgGeom wgm;
-            const bool pipe_ok = pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pg, model_traits(p->model_id).contrib_doubles) == 0;
-            const bool wg_ok = !wide_q && wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0;
+            bool pipe_ok = pipe_geometry(p->nq, p->n_contrib, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pg, model_traits(p->model_id).contrib_doubles) == 0;
+            bool wg_ok = !wide_q && wg_geometry(p->nq, p->n_contrib, TABD(WG_MAX_WAVES), WG_MAX_WAVES, &wgm) == 0;
+            // MCSAS_EXEC_AUTO never picks a mode whose working set does not fit the device: the speculative modes
+            // NEED their row cache (N + 2 windows of rows per chain) and the pipeline its window buffers on top (d rows, Gram blocks,
+            // scalars, proposals: 2 Kb (qpad + W + 4 + P) doubles per chain) — against half of what is free, the same rule the
+            // allocation below applies; one wavefront per chain runs without a cache when it must.  An explicitly requested mode
+            // still fails with MCSAS_ENOMEM.
+            {
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+                    const double Rd = (double)p->n_reps, row = 8.0 * (double)qpad;
+                    if (pipe_ok) {
+                        const double need = Rd * (((double)p->n_contrib + 2.0 * pg.kb + 1.0) * row
+                                                  + 2.0 * pg.kb * (row + 8.0 * (pg.w + 4 + MCSAS_MAX_ACTIVE) + 4.0));
+                        if (need >= 0.5 * (double)fr) pipe_ok = false;
+                    }
+                    if (wg_ok && Rd * ((double)p->n_contrib + 2.0 * wgm.window + 1.0) * row >= 0.5 * (double)fr) wg_ok = false;
+                }
+            }
             if (!heavy_rows) {
                 // rows without an integral: the mode with the highest MEASURED rate at the nearest swept shape
                 // (auto_table.h: 128..1024 q slots x 200..1000 contributions x 64..3000 repetitions on a 256-CU MI355X;
@@ -1773,6 +1791,12 @@ extern "C" int mcsas_hip_histogram(const mcsas_problem *p, const double *contrib
     hin.bytes = sizeof(double) * n_in; hback.bytes = sizeof(double) * n_back;
     HIPCHK(cached_host_malloc((void **)&hin.p, hin.bytes, hipHostMallocDefault));
     HIPCHK(cached_host_malloc((void **)&hback.p, hback.bytes, hipHostMallocDefault));
+    // every early return below leaves copies / kernels queued on the null stream: wait for them before the staging blocks above
+    // (destroyed after this guard) go back to the cache, where the next call would overwrite them under the DMA
+    struct SyncGuard {
+        bool armed = true;
+        ~SyncGuard() { if (armed) (void)hipStreamSynchronize(nullptr); }
+    } sync_guard;
     double *w = hin.p;
     memcpy(w, p->q, sizeof(double) * Q); w += Q;
     memcpy(w, p->intensity, sizeof(double) * Q); w += Q;
@@ -1821,6 +1845,7 @@ extern "C" int mcsas_hip_histogram(const mcsas_problem *p, const double *contrib
     }
     HIPCHK(hipMemcpyAsync(hback.p, dback.p, hback.bytes, hipMemcpyDeviceToHost, nullptr));
     HIPCHK(hipStreamSynchronize(nullptr));
+    sync_guard.armed = false;
     memcpy(scaling, hback.p, sizeof(double) * 2 * R);
     if (fractions) memcpy(fractions, hback.p + 2 * R, sizeof(double) * 8 * NR);
     if (n_out) memcpy(out, hback.p + 2 * R + 8 * NR, sizeof(double) * n_out);
@@ -1875,6 +1900,174 @@ extern "C" int mcsas_hip_rebin(int32_t n, const double *x, const double *f, cons
 }
 
 // streams for hosts without a HIP binding of their own (ctypes / cgo callers that want analyses on several streams)
+// ------------------------------------------------------------------------------ rows evaluated by the caller (ABI 4)
+// Philox4x32-10 on the host: the stream of device_util.h's philox_uniform (counter = (idx >> 1, chain, 0), key = seed; even draws
+// take words 0,1, odd draws words 2,3; 53 bits)
+static double philox_uniform_host(uint64_t seed, uint32_t chain, uint64_t idx) {
+    const uint64_t blk = idx >> 1;
+    uint32_t c0 = (uint32_t)blk, c1 = (uint32_t)(blk >> 32), c2 = chain, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t a = (idx & 1) ? c2 : c0, b = (idx & 1) ? c3 : c1;
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+extern "C" int mcsas_hip_analyse_host_rows(const mcsas_problem *p, mcsas_rows_callback rows_cb, void *user, int32_t window,
+                                           mcsas_result *res) {
+    if (!p || !rows_cb || !res) return fail(MCSAS_EINVAL, "null argument");
+    if (p->struct_size != sizeof(mcsas_problem))
+        return fail(MCSAS_EINVAL, "mcsas_problem size %u, library expects %zu (ABI mismatch)", p->struct_size, sizeof(mcsas_problem));
+    if (p->nq < 1 || p->nq > 16384 || !p->q || !p->intensity || !p->sigma) return fail(MCSAS_EINVAL, "nq %d (1..16384) / data pointers", p->nq);
+    if (p->n_active < 1 || p->n_active > MCSAS_MAX_ACTIVE) return fail(MCSAS_EINVAL, "n_active %d (1..%d)", p->n_active, MCSAS_MAX_ACTIVE);
+    if (p->n_contrib < 1 || p->n_reps < 1 || p->max_iter < 0 || p->max_retries < 0) return fail(MCSAS_EINVAL, "n_contrib / n_reps / max_iter / max_retries");
+    if (p->reserved0) return fail(MCSAS_EINVAL, "reserved0 must be 0");
+    for (int c = 0; c < p->n_active; ++c)
+        if (p->gen_kind[c] < MCSAS_GEN_UNIFORM || p->gen_kind[c] > MCSAS_GEN_EXP3) return fail(MCSAS_EINVAL, "gen_kind[%d] = %d", c, p->gen_kind[c]);
+    if (window < 1) window = 64;
+    DeviceGuard guard;
+    { int rc = select_device(p->device); if (rc) return rc; }
+    const size_t R = p->n_reps, N = p->n_contrib, P = p->n_active, Q = p->nq, qpad = (Q + 63) / 64 * 64;
+    const auto t_begin = std::chrono::steady_clock::now();
+
+    // data vectors (sigma == 0 -> 1, backgroundscalingfit.py:117) and their sums, as mcsas_hip_plan_create prepares them
+    std::vector<double> hw(qpad, 0.), hwI(qpad, 0.), hI(qpad, 0.);
+    double Sw = 0, SI = 0, SII = 0, Ss2 = 0;
+    for (size_t i = 0; i < Q; ++i) {
+        const double e = p->sigma[i] == 0.0 ? 1.0 : p->sigma[i], w = 1.0 / (e * e);
+        hw[i] = w; hwI[i] = w * p->intensity[i]; hI[i] = p->intensity[i];
+        Sw += w; SI += w * p->intensity[i]; SII += w * p->intensity[i] * p->intensity[i]; Ss2 += e * e;
+    }
+    DevBuf<double> dw, dwI, dI, drset, dcache, dft, dfit, drows, dpv;
+    DevBuf<FeedState> dstate;
+    DevBuf<int32_t> dmeta;
+    // rows per round: every chain's block is at most max(N, window) rows; as many chains per round as fit ~256 MB of staging
+    const size_t blk = std::max(N, (size_t)window);
+    const size_t round_rows = std::max(blk, std::min(R * blk, (size_t)(256u << 20) / (qpad * sizeof(double))));
+    HIPCHK(dw.alloc(qpad)); HIPCHK(dwI.alloc(qpad)); HIPCHK(dI.alloc(qpad));
+    HIPCHK(drset.alloc(R * N * P)); HIPCHK(dcache.alloc(R * N * qpad)); HIPCHK(dft.alloc(R * qpad)); HIPCHK(dfit.alloc(R * qpad));
+    HIPCHK(drows.alloc(round_rows * qpad)); HIPCHK(dpv.alloc(round_rows * P)); HIPCHK(dstate.alloc(R)); HIPCHK(dmeta.alloc(3 * R));
+    HIPCHK(hipMemcpy(dw.p, hw.data(), sizeof(double) * qpad, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dwI.p, hwI.data(), sizeof(double) * qpad, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dI.p, hI.data(), sizeof(double) * qpad, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dstate.p, 0, sizeof(FeedState) * R));
+    HIPCHK(hipMemset(dfit.p, 0, sizeof(double) * R * qpad));
+
+    FeedArgs fa;
+    memset(&fa, 0, sizeof fa);
+    ChainArgs &a = fa.c;
+    a.model.n_active = (int)P;
+    a.nq = (int)Q; a.qpad = (int)qpad; a.w = dw.p; a.wI = dwI.p; a.I = dI.p; a.Sw = Sw; a.SI = SI; a.SII = SII; a.Ssig2 = Ss2;
+    a.n_contrib = (int)N; a.n_reps = (int)R; a.find_bg = p->find_background; a.pos_bg = p->positive_background;
+    a.start_from_min = p->start_from_minimum; a.max_retries = p->max_retries; a.max_iter = p->max_iter; a.conv_crit = p->conv_crit;
+    a.rset = drset.p; a.cache = dcache.p; a.cache_rows = (int)N; a.fit = dfit.p;
+    fa.ft = dft.p; fa.state = dstate.p; fa.rows = drows.p; fa.pvals = dpv.p;
+    fa.first = dmeta.p; fa.count = dmeta.p + R; fa.kind = dmeta.p + 2 * R;
+
+    // the chains as the host sees them: where each is in its random stream and in the retry loop of McSAS.analyse (mcsas.py:220-246)
+    struct HostChain { uint64_t draw_pos = 0; int64_t num_iter = 0, total = 0; int attempt = 0, phase = 0 /*0 init due, 1 running, 2 done*/, converged = 0, overflow = 0, stopped = 0; double seconds = 0; };
+    std::vector<HostChain> hc(R);
+    std::vector<FeedState> hs(R);
+    std::vector<int32_t> meta(3 * R);
+    std::vector<double> pset(round_rows * P), hrows(round_rows * Q), staged(round_rows * qpad, 0.);
+    auto uniform = [&](size_t r, uint64_t idx, int *ovf) -> double {
+        if (p->replay_stream) {
+            if ((int64_t)idx < p->replay_len) return p->replay_stream[r * (size_t)p->replay_len + idx];
+            *ovf = 1;
+            return 0.5;
+        }
+        return philox_uniform_host(p->seed, (uint32_t)(p->rep_offset + (int)r), idx);
+    };
+    auto generate = [&](int c, double u) -> double {                      // numbergenerator.py:28-31,168-191; parameter.py:66-84
+        if (p->gen_kind[c] != MCSAS_GEN_UNIFORM) {
+            const double up = (double)p->gen_kind[c];
+            u = (std::pow(10.0, 0.0 + (up - 0.0) * u) - 1.0) / (p->gen_kind[c] == 1 ? 10.0 : (p->gen_kind[c] == 2 ? 100.0 : 1000.0));
+        }
+        return u * (p->gen_hi[c] - p->gen_lo[c]) + p->gen_lo[c];
+    };
+    size_t done = 0;
+    int64_t rounds = 0;
+    bool stop_seen = false;
+    while (done < R) {
+        if (p->stop && *p->stop) stop_seen = true;
+        size_t nrows = 0;
+        std::fill(meta.begin(), meta.end(), 0);
+        for (size_t r = 0; r < R; ++r) {
+            HostChain &h = hc[r];
+            if (h.phase == 2) continue;
+            if (stop_seen) {                                                    // McSAS.stop (mcsas.py:357): end every chain where it is
+                if (h.phase == 1) { meta[2 * R + r] = FEED_END; h.stopped = 1; }
+                else { h.phase = 2; h.stopped = 1; ++done; }
+                continue;
+            }
+            const size_t want = h.phase == 0 ? N : (size_t)std::min<int64_t>(window, p->max_iter - h.num_iter);
+            if (nrows + want > round_rows) continue;                            // next round
+            meta[r] = (int32_t)nrows; meta[R + r] = (int32_t)want; meta[2 * R + r] = h.phase == 0 ? FEED_INIT : FEED_STEPS;
+            for (size_t k = 0; k < want; ++k)
+                for (size_t c = 0; c < P; ++c) {
+                    double v;
+                    if (h.phase == 0) v = p->start_from_minimum ? p->start_value[c]     // mcsas.py:310-317: N draws per parameter, parameter-major
+                                                                : generate((int)c, uniform(r, h.draw_pos + c * N + k, &h.overflow));
+                    else v = generate((int)c, uniform(r, h.draw_pos + (uint64_t)(h.num_iter + (int64_t)k) * P + c, &h.overflow));   // :358
+                    pset[(nrows + k) * P + c] = v;
+                }
+            nrows += want;
+        }
+        if (nrows) {
+            // ScatteringModel.calc's loop body for every row (scatteringmodel.py:90-99): the caller's calcIntensity
+            const int rc = rows_cb(user, (int32_t)nrows, pset.data(), hrows.data());
+            if (rc) return fail(MCSAS_ECALLBACK, "rows callback returned %d", rc);
+            for (size_t i = 0; i < nrows; ++i) memcpy(&staged[i * qpad], &hrows[i * Q], sizeof(double) * Q);
+            HIPCHK(hipMemcpy(drows.p, staged.data(), sizeof(double) * nrows * qpad, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(dpv.p, pset.data(), sizeof(double) * nrows * P, hipMemcpyHostToDevice));
+        }
+        HIPCHK(hipMemcpy(dmeta.p, meta.data(), sizeof(int32_t) * 3 * R, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(feed_rows_kernel, dim3((unsigned)R), dim3(64), 0, nullptr, fa);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy(hs.data(), dstate.p, sizeof(FeedState) * R, hipMemcpyDeviceToHost));
+        ++rounds;
+        const double now = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        for (size_t r = 0; r < R; ++r) {
+            HostChain &h = hc[r];
+            const int kind = meta[2 * R + r];
+            if (h.phase == 2 || (meta[R + r] == 0 && kind != FEED_END)) continue;
+            if (kind == FEED_INIT) { h.phase = 1; h.num_iter = 0; if (!p->start_from_minimum) h.draw_pos += (uint64_t)N * P; }
+            h.num_iter = hs[r].num_iter;
+            if (hs[r].ended) {                                                  // the attempt is over (mcsas.py:424-439)
+                h.total += h.num_iter; h.draw_pos += (uint64_t)h.num_iter * P;
+                h.converged = hs[r].converged;
+                if (h.converged || h.stopped || h.attempt >= p->max_retries) { h.phase = 2; h.seconds = now; ++done; }
+                else { ++h.attempt; h.phase = 0; }                              // :220-246: the next attempt goes on in the stream
+            }
+        }
+    }
+    // results in the layout of mcsas_result (mcsas.py:203-210,233-251)
+    std::vector<double> hr(R * N * P), hf(R * qpad);
+    HIPCHK(hipMemcpy(hr.data(), drset.p, sizeof(double) * hr.size(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hf.data(), dfit.p, sizeof(double) * hf.size(), hipMemcpyDeviceToHost));
+    int ovf = 0;
+    for (size_t r = 0; r < R; ++r) {
+        if (res->contribs) for (size_t n = 0; n < N; ++n) for (size_t c = 0; c < P; ++c) res->contribs[(n * P + c) * R + r] = hr[(r * N + n) * P + c];
+        if (res->fit) for (size_t k = 0; k < Q; ++k) res->fit[k * R + r] = hf[r * qpad + k];
+        if (res->chisq) res->chisq[r] = hs[r].chi2;
+        if (res->scaling) res->scaling[r] = hs[r].A;
+        if (res->background) res->background[r] = hs[r].b;
+        if (res->num_iter) res->num_iter[r] = hs[r].num_iter;
+        if (res->num_moves) res->num_moves[r] = hs[r].num_moves;
+        if (res->attempts) res->attempts[r] = hc[r].attempt + 1;
+        if (res->converged) res->converged[r] = hc[r].converged;
+        if (res->seconds) res->seconds[r] = hc[r].seconds;
+        if (res->draws) res->draws[r] = (int64_t)hc[r].draw_pos;
+        ovf |= hc[r].overflow;
+    }
+    if (ovf) return fail(MCSAS_ESTREAM, "replay stream exhausted (replay_len=%lld)", (long long)p->replay_len);
+    return MCSAS_OK;
+}
+
 extern "C" int mcsas_hip_stream_create(int32_t device, void **stream) {
     if (!stream) return fail(MCSAS_EINVAL, "null argument");
     DeviceGuard dev_guard;

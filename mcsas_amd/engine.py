@@ -17,6 +17,7 @@ from ._lib import MAX_ACTIVE, MAX_DEVICES, MAX_PARAMS, Problem, Result, as_dp, c
 MODEL_SPHERE, MODEL_CYL_ISO, MODEL_ELL_CS, MODEL_KHOLODENKO = 0, 1, 2, 3
 MODEL_ELL_ISO, MODEL_SPH_CS, MODEL_GAUSS_CHAIN, MODEL_LMA_SPHERE = 4, 5, 6, 7
 MODEL_PLUGIN0 = 64      # first id of a run-time model plug-in (include/mcsas_hip.h: MCSAS_MODEL_PLUGIN0)
+MODEL_HOST = -1         # a model that exists only as host code (Python formfactor / volume): rows through analyse_host_rows
 
 
 class PluginCompileError(ValueError):
@@ -190,6 +191,34 @@ def analyse(model: ModelSetup, q, intensity, sigma, st: Settings, replay=None, s
     prob = HipProblem(model, q, intensity, sigma, st, replay, stop, smear)
     res = ChainResults(st.n_contrib, model.n_active, st.n_reps, len(prob.q))
     check(lib.mcsas_hip_analyse(C.byref(prob.c), C.byref(res.c)), lib)
+    return res
+
+
+def analyse_host_rows(model: ModelSetup, q, intensity, sigma, st: Settings, row_fn, replay=None, stop=None, window=64) -> ChainResults:
+    """McSAS.analyse for a model that exists only as host code (mcsas_hip_analyse_host_rows, include/mcsas_hip.h): the library draws
+    the proposals of the next `window` steps of every chain, `row_fn(pset[n][n_active]) -> rows[n][nq]` evaluates the caller's own
+    calcIntensity for all of them (bases/model/scatteringmodel.py:90-99, sasmodel.py:46-79), the device does the rest of mcFit."""
+    lib = _lib.load()
+    prob = HipProblem(model, q, intensity, sigma, st, replay, stop, None)
+    prob.c.model_id = MODEL_HOST
+    nq, P = len(prob.q), model.n_active
+    res = ChainResults(st.n_contrib, P, st.n_reps, nq)
+    failure = []
+
+    def cb(user, n, pset_p, rows_p):
+        try:
+            pset = np.ctypeslib.as_array(pset_p, shape=(n, P))
+            out = np.ctypeslib.as_array(rows_p, shape=(n, nq))
+            out[:, :] = np.asarray(row_fn(pset), dtype=np.float64).reshape(n, nq)
+            return 0
+        except BaseException as e:           # (an exception must not cross the C frame: hand it over and re-raise below)
+            failure.append(e)
+            return 1
+
+    rc = lib.mcsas_hip_analyse_host_rows(C.byref(prob.c), _lib.RowsCallback(cb), None, int(window), C.byref(res.c))
+    if failure:
+        raise failure[0]
+    check(rc, lib)
     return res
 
 

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import engine
 from .parameter import isActiveFitParam
-from .scatteringmodels import setup_from_model
+from .scatteringmodels import setup_from_model, host_model_calc
 
 
 class _Setting(object):
@@ -70,6 +70,7 @@ class McSAS(object):
         self.execMode = execMode
         self._stop = C.c_int32(0)
         self.details = None
+        self.hostRowWindow = 64          # proposals evaluated ahead per chain for models that exist only as Python (mcsas_hip.h)
 
     # McSAS.stop is polled once per step in the reference (mcsas.py:357); here the word is
     # forwarded to the running kernel by the library
@@ -116,8 +117,18 @@ class McSAS(object):
         else:
             numContribs, numReps = self.numContribs(), self.numReps()
         pr = self._problem(numContribs, numReps, replay)
-        res = engine.analyse(pr["model"], pr["q"], pr["intensity"], pr["sigma"], pr["st"],
-                             replay=pr["replay"], stop=pr["stop"], smear=pr["smear"])
+        if pr["model"].model_id == engine.MODEL_HOST:
+            # a model with Python formfactor / volume only: its rows are evaluated here, by the model's own calcIntensity with the
+            # set-value-and-restore semantics of ScatteringModel.calc (scatteringmodel.py:86-104); the device does the rest
+            c = self.compensationExponent()
+
+            def rows(pset):
+                return host_model_calc(model, data, pset, c, want_rows=True)[4]
+            res = engine.analyse_host_rows(pr["model"], pr["q"], pr["intensity"], pr["sigma"], pr["st"], rows,
+                                           replay=pr["replay"], stop=pr["stop"], window=self.hostRowWindow)
+        else:
+            res = engine.analyse(pr["model"], pr["q"], pr["intensity"], pr["sigma"], pr["st"],
+                                 replay=pr["replay"], stop=pr["stop"], smear=pr["smear"])
         self._store(res, numReps)
 
     def _problem(self, numContribs=None, numReps=None, replay=None):
@@ -175,6 +186,23 @@ class McSAS(object):
         smear = data.smearArgs(model) if hasattr(data, "smearArgs") else None
         c = self.compensationExponent()
         sig = np.array(data.f.binnedDataU, dtype=float)
+        if setup.model_id == engine.MODEL_HOST:
+            # rows by the model's own calcIntensity (:552, :577-578), the fit on the device (:559), the visibility limits in numpy (:575-590)
+            scalingFactors = np.zeros((2, numReps))
+            vsets = np.zeros((numContribs, numReps)); wsets = np.zeros((numContribs, numReps)); ssets = np.zeros((numContribs, numReps))
+            mv = np.zeros((numContribs, numReps))
+            for ri in range(numReps):
+                cum, vsets[:, ri], wsets[:, ri], ssets[:, ri], rows = host_model_calc(model, data, contribs[:, :, ri], c, want_rows=True)
+                sc, _, _ = engine.bgfit(data.f.binnedData, sig, cum, self.findBackground.value(), self.positiveBackground.value(),
+                                        num_params=model.activeParamCount(), device=self.device)
+                scalingFactors[:, ri] = sc
+                vf_r = wsets[:, ri] * sc[0] / vsets[:, ri]
+                for ci in range(numContribs):
+                    part = sc[0] * rows[ci]
+                    nz = part != 0.
+                    mv[ci, ri] = (sig[nz] * vf_r[ci] / part[nz]).min()
+            self._histogram_tail(contribs, scalingFactors, vsets, wsets, ssets, mv)
+            return
         # Everything on the device in one call (mcsas_hip_histogram): model.calc, the scale / background fit, the visibility
         # limits, the fractions, and per configured histogram the bins, CDF and moments of every repetition — their mean / std over
         # the repetitions is taken here.  (More than engine.HISTOGRAM_MAX_CONTRIBS contributions: the two-step path below.)
@@ -194,6 +222,11 @@ class McSAS(object):
         scalingFactors, vsets, wsets, ssets, mv = engine.histogram_prep(
             setup, data.q, data.f.binnedData, sig, contribs, c, self.findBackground.value(),
             self.positiveBackground.value(), device=self.device, smear=smear)
+        self._histogram_tail(contribs, scalingFactors, vsets, wsets, ssets, mv)
+
+    def _histogram_tail(self, contribs, scalingFactors, vsets, wsets, ssets, mv):
+        """mcsas.py:561-615 from the per-contribution volumes / weights / surfaces and visibility limits of every repetition."""
+        model = self.model
         vf = wsets * scalingFactors[0][None, :] / vsets          # modeldata.py:57-61
         nf = vf / vsets
         qf = vf * vsets

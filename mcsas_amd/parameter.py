@@ -249,7 +249,9 @@ class Moments(object):
             dev2 = dev * dev
             var = ssum(dev2 * fraction) / tot
             sigma = np.sqrt(np.abs(var))
-            ok = anyv & ((tot * sigma) != 0.0) & np.isfinite(tot * sigma)
+            # (utils/parameter.py:106-107 skips only an exact zero: a NaN product — all-zero weighting, e.g. 'surf' on a model
+            # without surface() — goes on and gives NaN skew / kurtosis, like the variance)
+            ok = anyv & ((tot * sigma) != 0.0)
             sigma2 = sigma * sigma
             skw = np.where(ok, ssum(dev2 * dev * fraction) / (tot * (sigma2 * sigma)), 0.0)
             krt = np.where(ok, ssum(dev2 * dev2 * fraction) / (tot * (sigma2 * sigma2)), 0.0)

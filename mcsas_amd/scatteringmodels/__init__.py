@@ -80,14 +80,56 @@ class ScatteringModel(object):
         return setup_from_model(self, data)
 
     def calc(self, data, pset, compensationExponent=None):   # scatteringmodel.py:79-105, on the GPU
+        if is_host_model(self):                              # a model of the user's own with Python formfactor / volume only
+            return self.getModelData(*host_model_calc(self, data, np.asarray(pset, dtype=float), compensationExponent)[:4])
         q = data.q if hasattr(data, "q") else np.asarray(data)
         smear = data.smearArgs(self) if hasattr(data, "smearArgs") else None    # sasmodel.py:56-60
         cum, v, w, s = engine.model_calc(self.setup(), q, pset, compensationExponent, smear=smear)
         return self.getModelData(cum, v, w, s)
 
+    # ---- what a model of the user's own supplies in Python (bases/model/scatteringmodel.py:15-58); the built-in models never
+    # call these: their arithmetic is in csrc/models.h
+    def volume(self):
+        raise NotImplementedError
+
+    def absVolume(self):                                     # scatteringmodel.py:22-25
+        return self.volume()
+
+    def surface(self):                                       # :53-57
+        return 0
+
+    def formfactor(self, dataset):
+        raise NotImplementedError
+
 
 class SASModel(ScatteringModel):
     canSmear = False
+    compensationExponent = None
+
+    def getQ(self, dataset):                                 # sasmodel.py:27-35
+        return dataset if isinstance(dataset, np.ndarray) else dataset.q
+
+    def weight(self):                                        # sasmodel.py:37-44
+        return self.volume() ** (2 * self.compensationExponent)
+
+    def calcIntensity(self, data, compensationExponent=None):
+        """sasmodel.py:46-79 for a model with Python formfactor / volume: (it, v, w, s) of the CURRENT parameter values."""
+        self.compensationExponent = compensationExponent
+        v = self.absVolume()
+        w = self.weight()
+        s = self.surface()
+        sm = getattr(getattr(data, "config", None), "smearing", None)
+        if sm is not None and self.canSmear and sm.doSmear() and sm.inputValid():
+            ff = self.formfactor(data.locs)
+            qOffset, weightFunc = sm.prepared
+            it = 2 * _trapz(ff ** 2 * w * weightFunc, x=qOffset, axis=1)
+        else:
+            ff = self.formfactor(data)
+            it = ff ** 2 * w
+        return it, v, w, s
+
+
+_trapz = getattr(np, "trapezoid", None) or np.trapz
 
 
 def _fp(*a, **k):
@@ -320,6 +362,45 @@ MODEL_IDS = {"Sphere": engine.MODEL_SPHERE, "CylindersIsotropic": engine.MODEL_C
              "GaussianChain": engine.MODEL_GAUSS_CHAIN, "LMADenseSphere": engine.MODEL_LMA_SPHERE}
 
 
+def is_host_model(model) -> bool:
+    """A model without a kernel id, without a shipped plug-in text and without `hipSource`, but with the reference's Python
+    contract (calcIntensity, i.e. formfactor + volume: bases/model/sasmodel.py:46-79): its rows are evaluated by the host."""
+    if getattr(model, "model_id", None) is not None or type(model).__name__ in MODEL_IDS:
+        return False
+    if isinstance(getattr(model, "hipSource", None), str) or type(model).__name__ in SHIPPED_PLUGINS:
+        return False
+    if isinstance(model, ScatteringModel):                  # our mirror base: the subclass must bring formfactor AND volume
+        return type(model).formfactor is not ScatteringModel.formfactor and type(model).volume is not ScatteringModel.volume
+    return callable(getattr(model, "calcIntensity", None))  # the reference's own classes: ABCMeta enforces the rest
+
+
+def host_model_calc(model, data, pset, compensationExponent, want_rows=False):
+    """ScatteringModel.calc (bases/model/scatteringmodel.py:79-105) for a host model, ours or the reference's own object: remember the
+    active parameters' values, per parameter set p.setValue(v) (which clips into the valueRange) and calcIntensity, rows summed
+    in order, values restored.  -> (cumInt, vset, wset, sset, rows or None)."""
+    params = model.activeParams()
+    old = [p() for p in params]
+    pset = np.asarray(pset, dtype=float).reshape(-1, len(params))
+    cum = None
+    vset = np.zeros(len(pset)); wset = np.zeros(len(pset)); sset = np.zeros(len(pset))
+    rows = [] if want_rows else None
+    try:
+        for i, row in enumerate(pset):
+            for p, v in zip(params, row):
+                p.setValue(float(v))
+            it, vset[i], wset[i], sset[i] = model.calcIntensity(data, compensationExponent=compensationExponent)
+            it = np.asarray(it, dtype=float).flatten()
+            cum = it.copy() if cum is None else cum + it
+            if want_rows:
+                rows.append(it)
+    finally:
+        for p, v in zip(params, old):
+            p.setValue(v)
+    if cum is None:
+        cum = np.zeros(0)
+    return cum, vset, wset, sset, (np.array(rows) if want_rows else None)
+
+
 def setup_from_model(model, data=None) -> engine.ModelSetup:
     """Flattens a configured model instance — ours or the reference's own (duck-typed through
     params()/name()/value()/isActive()/activeRange()/valueRange()/generator()) — into the
@@ -333,9 +414,13 @@ def setup_from_model(model, data=None) -> engine.ModelSetup:
         # a model of the user's own (the reference: any models/*.py, utils/findmodels.py:120-186): its form factor as HIP
         # source text, compiled at run time into the wave-per-chain kernel (engine.compile_plugin)
         mid = engine.compile_plugin(model.hipSource)
+    if mid is None and is_host_model(model):
+        # Python formfactor / volume only (the reference's plug-in contract as it stands): the chains run with host-evaluated
+        # rows (mcsas_hip_analyse_host_rows); everything but the rows stays on the device
+        mid = engine.MODEL_HOST
     if mid is None:
-        raise NotImplementedError("model %s has no HIP kernel (built in: %s; any other model needs a `hipSource` "
-                                  "attribute, see INTEGRATION.md)" % (type(model).__name__, ", ".join(MODEL_IDS)))
+        raise NotImplementedError("model %s has no HIP kernel (built in: %s), no `hipSource` text and no Python calcIntensity "
+                                  "(formfactor + volume) either: see INTEGRATION.md" % (type(model).__name__, ", ".join(MODEL_IDS)))
     params = list(model.params())
     if len(params) > engine.MAX_PARAMS:
         raise NotImplementedError("model %s has %d parameters, the C ABI carries %d" % (type(model).__name__, len(params), engine.MAX_PARAMS))

@@ -1079,6 +1079,34 @@ def gen_converging_trajectories(which=("cyl", "ellcs", "posbg")):
         save_traj(name, data_vectors(d), s, run_mcfit(algo, 200, seed))
 
 
+def gen_moments_edge_cases():
+    """G19 — utils/parameter.py:20-122 (Moments) on weightings the fit never produces but histogram() can: fractions that are all
+    zero ('surf' weighting of a model without surface(): variance 0/0 = NaN, and since NaN == 0.0 is False the reference goes on to
+    NaN skew / kurtosis), a repetition with no contribution inside the range (skipped: zeros), a one-member range (sigma = 0: skew
+    and kurtosis skipped) and an ordinary case."""
+    from mcsas.utils.parameter import Moments
+    rs = np.random.RandomState(19)
+    out = {}
+    contribs = rs.uniform(1.0, 10.0, size=(40, 2, 3))
+    cases = {"ordinary": (rs.uniform(0.0, 1.0, size=(40, 3)), (2.0, 9.0)),
+             "zero_weight": (np.zeros((40, 3)), (2.0, 9.0)),
+             "one_rep_zero": (np.concatenate([rs.uniform(0.0, 1.0, size=(40, 2)), np.zeros((40, 1))], axis=1), (2.0, 9.0)),
+             "empty_range": (rs.uniform(0.0, 1.0, size=(40, 3)), (20.0, 30.0))}
+    c1 = contribs.copy(); c1[:, 0, 1] = 50.0; c1[7, 0, 1] = 5.0            # repetition 1: ONE member inside the range
+    with np.errstate(all="ignore"):
+        for name, (frac, rng) in cases.items():
+            m = Moments(contribs, 0, rng, frac)
+            out[name + "_fraction"] = frac; out[name + "_range"] = np.array(rng); out[name + "_fields"] = np.array(m.fields, dtype=float)
+        frac = cases["ordinary"][0]
+        m = Moments(c1, 0, (2.0, 9.0), frac)
+        out["one_member_fraction"] = frac; out["one_member_range"] = np.array((2.0, 9.0)); out["one_member_fields"] = np.array(m.fields, dtype=float)
+    out["contribs"] = contribs; out["contribs_one_member"] = c1
+    np.savez_compressed(os.path.join(OUT, "g19_moments_edge.npz"), **out)
+    for k in sorted(out):
+        if k.endswith("_fields"):
+            print("G19", k, out[k])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     quiet_logging(None)
@@ -1123,5 +1151,7 @@ if __name__ == "__main__":
         gen_converging_trajectories()
     if "converge_posbg" in which:
         gen_converging_trajectories(("posbg",))
+    if "moments" in which or not sys.argv[1:]:
+        gen_moments_edge_cases()
     if "cylradiso" in which or not sys.argv[1:]:
         gen_cyl_radially_isotropic()

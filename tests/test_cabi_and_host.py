@@ -169,6 +169,20 @@ def test_histogram_host_binning_matches_reference(golden_dir):
         np.testing.assert_allclose(np.array(h.moments.fields)[0::2], g[p + "moments"][0::2], rtol=1e-9)
 
 
+@pytest.mark.parametrize("case", ["ordinary", "zero_weight", "one_rep_zero", "empty_range", "one_member"])
+def test_moments_edge_cases_match_the_reference(golden_dir, case):
+    """Moments (utils/parameter.py:84-122) where a weighting sums to zero, a repetition has nothing in range or a single member
+    (fixture G19, oracle/make_golden.py gen_moments_edge_cases, from the reference's own class): only an EXACT zero of
+    sum(frac) * sigma is skipped — an all-zero weighting gives NaN variance AND NaN skew / kurtosis, as in the reference."""
+    from mcsas_amd.parameter import Moments
+    g = np.load(os.path.join(golden_dir, "g19_moments_edge.npz"))
+    contribs = g["contribs_one_member"] if case == "one_member" else g["contribs"]
+    with np.errstate(all="ignore"):
+        m = Moments(contribs, 0, tuple(g[case + "_range"]), g[case + "_fraction"])
+    np.testing.assert_allclose(np.array(m.fields, dtype=float), g[case + "_fields"], rtol=1e-9, atol=1e-300, equal_nan=True)
+    assert np.isnan(g["zero_weight_fields"][4:]).all()          # (what the fixture pins)
+
+
 def test_shard_rule_of_the_library_is_the_one_of_dist():
     """mcsas_hip_shard (how mcsas_hip_analyse splits repetitions over a device list) == mcsas_amd.dist.shard_reps (how
     bench.py's ranks split them): contiguous blocks in order, sizes within one of each other, empty blocks allowed."""

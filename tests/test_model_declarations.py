@@ -135,3 +135,58 @@ def test_reference_model_objects_flatten_like_the_mirror(cls):
     np.random.seed(5)
     g = np.asarray(ref_model.generateParameters(64), dtype=float)
     assert (g >= a.gen_lo).all() and (g <= a.gen_hi).all()
+
+
+def test_a_reference_model_that_exists_only_as_python_runs_through_host_rows():
+    """A model of the user's own written against the REFERENCE's plug-in API — a SASModel subclass with numpy formfactor() /
+    volume() / absVolume() and nothing else (bases/model/scatteringmodel.py:16-58, sasmodel.py:37-79; here the Guinier law of a
+    sphere, which no built-in kernel has) — flattens to the host-rows path (engine.MODEL_HOST: mcsas_hip_analyse_host_rows), and
+    the row evaluation the library will call back (scatteringmodels.host_model_calc: set values, calcIntensity, restore) gives
+    the reference's own model.calc() bit for bit and leaves the model's parameter values where they were."""
+    _import_reference()
+    import numpy
+    from mcsas.bases.algorithm import RandomExponential
+    from mcsas.utils.parameter import FitParameter, Parameter
+    from mcsas.bases.model import SASModel
+    from mcsas.dataobj.sasdata import SASData
+    from mcsas_amd import engine
+
+    class GuinierSphere(SASModel):
+        shortName = "Guinier sphere (user model)"
+        parameters = (FitParameter("rg", 5e-9, displayName="radius of gyration", generator=RandomExponential,
+                                   valueRange=(1e-10, 1e-6), activeRange=(1e-9, 1e-7)),
+                      Parameter("sld", 1e14, displayName="contrast", valueRange=(0., numpy.inf)))
+
+        def __init__(self):
+            super(GuinierSphere, self).__init__()
+            self.rg.setActive(True)
+
+        def volume(self):
+            r = self.rg() * numpy.sqrt(5. / 3.)
+            return (numpy.pi * 4. / 3.) * r**3
+
+        def absVolume(self):
+            return self.volume() * self.sld()**2
+
+        def formfactor(self, dataset):
+            q = self.getQ(dataset)
+            return numpy.exp(-(q * self.rg())**2 / 6.)
+
+    GuinierSphere.factory()
+    m = GuinierSphere()
+    m.rg.setActiveRange((2e-9, 5e-8))
+    assert SM.is_host_model(m)
+    setup = SM.setup_from_model(m)
+    assert setup.model_id == engine.MODEL_HOST and setup.active_index == (0,) and setup.gen_kind == (1,)
+    np.testing.assert_array_equal(setup.gen_lo, [2e-9]); np.testing.assert_array_equal(setup.gen_hi, [5e-8])
+    q_nm = np.logspace(-2, 0.3, 40)
+    d = SASData(title="syn", rawArray=np.stack([q_nm, np.ones(40), 0.01 * np.ones(40)], axis=1))
+    d.config.nBin.setValue(0); d._reBin()
+    pset = np.array([[3e-9], [1e-8], [4.9e-8], [1e-12], [1.0]])       # the last two are clipped by setValue (valueRange)
+    before = m.rg()
+    ref = m.calc(d, pset, 0.6666666)                                   # the reference's own ScatteringModel.calc
+    cum, v, w, s_, rows = SM.host_model_calc(m, d, pset, 0.6666666, want_rows=True)
+    assert m.rg() == before
+    np.testing.assert_array_equal(cum, ref.cumInt); np.testing.assert_array_equal(v, ref.vset); np.testing.assert_array_equal(w, ref.wset)
+    assert rows.shape == (5, 40) and np.isfinite(rows).all()
+    np.testing.assert_array_equal(rows[3], SM.host_model_calc(m, d, [[1e-10]], 0.6666666, want_rows=True)[4][0])   # clipped to the range's edge

@@ -434,6 +434,114 @@ def test_mcsas_front_end_device_list_with_an_integral_model_in_auto_mode():
         np.testing.assert_array_equal(a, b)
 
 
+class PythonOnlySphere(mcsas_amd.SASModel):
+    """models/sphere.py:12-63 typed again the way a user of the reference writes a model: declarations + numpy formfactor / volume /
+    absVolume / surface — no kernel id, no HIP text."""
+    shortName = "Sphere (Python only)"
+    canSmear = True
+    parameters = mcsas_amd.Sphere.parameters
+
+    def __init__(self):
+        super().__init__()
+        self.radius.setActive(True)
+
+    def surface(self):
+        return 4. * np.pi * self.radius() * self.radius()
+
+    def volume(self):
+        return (np.pi * 4. / 3.) * self.radius()**3
+
+    def absVolume(self):
+        return self.volume() * self.sld()**2
+
+    def formfactor(self, dataset):
+        qr = self.getQ(dataset) * self.radius()
+        return 3. * (np.sin(qr) - qr * np.cos(qr)) / (qr**3.)
+
+
+def test_python_only_model_replays_the_reference_through_host_rows():
+    """A ScatteringModel that exists only as Python (the reference's plug-in contract as it stands: scatteringmodel.py:16-58,
+    sasmodel.py:37-79) runs through McSAS.calc(): the library draws the proposals, calls back into the model's own calcIntensity
+    for the rows of a window (mcsas_hip_analyse_host_rows) and takes every decision on the device.  Fed the uniform stream the
+    reference consumed (g4_sphere_q100_fixed), it reproduces the reference's chain: iterations, accepted moves, parameter set exact,
+    chi² 1e-9 — and equals the built-in sphere kernel run on the same stream; histogram() works on the result."""
+    g, m_builtin, spec, st, ost = traj_setup("g4_sphere_q100_fixed.npz")
+    assert mcsas_amd.scatteringmodels.is_host_model(PythonOnlySphere())
+    out = {}
+    for tag, cls in (("python", PythonOnlySphere), ("builtin", mcsas_amd.Sphere)):
+        m = cls()
+        lo, hi = float(g["spec_lo"][0]), float(g["spec_hi"][0])
+        m.radius.setActiveRange((lo, hi)); m.sld.setValue(float(g["spec_sld"]))
+        m.radius.histograms().append(mcsas_amd.Histogram(m.radius, lo, hi, binCount=20, xscale='log', yweight='vol'))
+        algo = mcsas_amd.McSAS(seed=1)
+        algo.numContribs.setValue(st.n_contrib); algo.numReps.setValue(1); algo.maxIterations.setValue(st.max_iter)
+        algo.convergenceCriterion.setValue(st.conv_crit); algo.compensationExponent.setValue(st.comp_exp); algo.showIncomplete.setValue(True)
+        algo.maxRetries = mcsas_amd.mcsas._Setting("maxRetries", 0)
+        algo.hostRowWindow = 37                                   # (a window that does not divide the budget)
+        algo.model = m
+        algo.data = mcsas_amd.SASData(g["data_q"], g["data_I"], g["data_sigma"], f_limit=g["data_f_limit"])
+        algo.calc(replay=g["stream"][None, :])
+        d = algo.details
+        out[tag] = (algo.result[0]["contribs"].copy(), d.chisq.copy(), np.asarray(m.radius.histograms()[0].bins.mean).copy())
+        assert d.num_iter[0] == int(g["res_num_iter"]) and d.num_moves[0] == int(g["res_num_moves"]), tag
+        np.testing.assert_allclose(algo.result[0]["contribs"][:, :, 0], g["res_rset"], rtol=1e-15)
+        np.testing.assert_allclose(d.chisq[0], float(g["res_conval"]), rtol=1e-9)
+        np.testing.assert_allclose(algo.result[0]["fitMeasValMean"][0], g["res_fit"], rtol=1e-6)
+    np.testing.assert_array_equal(out["python"][0], out["builtin"][0])
+    np.testing.assert_allclose(out["python"][1], out["builtin"][1], rtol=1e-12)
+    np.testing.assert_allclose(out["python"][2], out["builtin"][2], rtol=1e-9, atol=1e-300)
+
+
+def test_python_only_model_free_running_retries_and_stop():
+    """Host rows, free-running: several chains with a criterion some reach within the budget and some only in a later attempt
+    (the retry loop of mcsas.py:220-246 is followed between windows, the random stream goes on where the attempt stopped), against
+    the numpy oracle on the same Philox streams; and McSAS.stop raised by the model's own callback ends every chain where it is."""
+    g = load("g4_sphere_q100_fixed.npz")
+    q, I, sig = g["data_q"], g["data_I"], g["data_sigma"]
+    lo, hi = float(g["spec_lo"][0]), float(g["spec_hi"][0])
+    m = PythonOnlySphere(); m.radius.setActiveRange((lo, hi)); m.sld.setValue(float(g["spec_sld"]))
+    _, spec = make_models("sphere", [lo], [hi], sld=float(g["spec_sld"]))
+    data = mcsas_amd.SASData(q, I, sig, f_limit=g["data_f_limit"])
+    st = engine.Settings(n_contrib=60, n_reps=5, max_iter=400, conv_crit=350.0, max_retries=2, seed=77, rep_offset=3)
+    setup = m.setup(data)
+
+    def rows(pset):
+        return mcsas_amd.scatteringmodels.host_model_calc(m, data, pset, st.comp_exp, want_rows=True)[4]
+    res = engine.analyse_host_rows(setup, q, I, sig, st, rows, window=50)
+    ost = O.Settings(n_contrib=60, n_reps=1, max_iter=400, conv_crit=350.0, max_retries=2)
+    attempts = []
+    for r in range(5):
+        stream = O.PhiloxStream(77, 3 + r)
+        for att in range(3):
+            ref = O.mc_fit(spec, q, I, sig, g["data_f_limit"], g["data_x0_limit"], ost, stream, method="closed")
+            if ref.conval <= 350.0:
+                break
+        attempts.append(att + 1)
+        assert res.attempts[r] == att + 1 and res.num_iter[r] == ref.num_iter and res.num_moves[r] == ref.num_moves, r
+        assert res.draws[r] == stream.pos
+        np.testing.assert_allclose(res.contribs[:, :, r], ref.rset, rtol=1e-13)
+        np.testing.assert_allclose(res.chisq[r], ref.conval, rtol=1e-9)
+    assert sorted(set(attempts)) == [1, 2, 3] and res.converged.sum() == 4      # (one chain misses the criterion in all three attempts)
+    # stop: raised inside the third callback
+    import ctypes
+    stop = ctypes.c_int32(0)
+    calls = []
+
+    def rows_then_stop(pset):
+        calls.append(len(pset))
+        if len(calls) == 3:
+            stop.value = 1
+        return rows(pset)
+    st2 = engine.Settings(n_contrib=60, n_reps=4, max_iter=100000, conv_crit=0.0, max_retries=0, seed=5)
+    res2 = engine.analyse_host_rows(setup, q, I, sig, st2, rows_then_stop, stop=stop, window=40)
+    assert len(calls) == 3 and (res2.num_iter == 80).all() and (res2.converged == 0).all() and np.isfinite(res2.chisq).all()
+    # a callback that raises: the exception comes back to the caller, nothing hangs
+    def bad(pset):
+        raise ZeroDivisionError("model failed")
+    with pytest.raises(ZeroDivisionError):
+        engine.analyse_host_rows(setup, q, I, sig, st2, bad)
+
+
 @pytest.mark.parametrize("waves", [1, 8, 5, -3])
 def test_free_running_philox_matches_oracle(waves):
     """Free-running chains (device Philox) follow the oracle run with the same counter-based stream:
