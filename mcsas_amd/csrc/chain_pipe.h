@@ -205,7 +205,7 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         g->scan_waves = PIPE_WAVES;
         g->scan_lds = sizeof(double) * ((size_t)g->w * qpad + 2 * (size_t)g->w * g->w + 3 * (size_t)qpad + (size_t)g->kb * 4 + 64)
                     + sizeof(int32_t) * (4 * (size_t)g->kb + 1 + 1 + 64 + 4 + 8) + 64;
-        if (g->scan_lds > 160 * 1024 || g->prod_lds > 160 * 1024) return 1;
+        if (g->scan_lds > 160 * 1024 || g->prod_lds > 160 * 1024) return 2;     // (2: the window's records / row buffers do not fit the LDS)
         return 0;
     }
     // window: as many steps as 2*Kb <= N allows, Kb = (sub-windows) x (8 producer waves) x (rows per wave).
@@ -294,7 +294,7 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
     // the sub-window, flags / slot tables / accepted lists
     g->scan_lds = sizeof(double) * ((size_t)g->w * qpad + 2 * (size_t)g->w * g->w + 2 * (size_t)qpad + (size_t)g->kb * 4 + 64)
                 + sizeof(int32_t) * (4 * (size_t)g->kb + 1 + 1 + 64 + 4 + 8) + 64;
-    if (g->scan_lds > 160 * 1024 || g->prod_lds > 160 * 1024) return 1;
+    if (g->scan_lds > 160 * 1024 || g->prod_lds > 160 * 1024) return 2;
     return 0;
 }
 
@@ -1544,7 +1544,8 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
             wq[x] = 0.;
             if (i < qpad) { wq[x] = gw_[i]; lft[i] = gft[i]; lwft[i] = gwft[i]; if constexpr (RQ) lwq[i] = wq[x]; }
         }
-        if (tid < kmax_all) {                                  // Kb <= 256 < threads
+        static_assert(PIPE_BLOCK >= 512, "one window step per thread: pipe_geometry caps Kb at PIPE_BLOCK");
+        if (tid < kmax_all) {                                  // Kb <= PIPE_BLOCK = threads (pipe_geometry)
             osub[tid] = povf[tid];
             if (!pa.g.lazy_rows) {                             // (lazy rows never move: no slot tables)
                 int r = ri0 + tid; if (r >= N) r -= N;
@@ -1665,7 +1666,7 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     constexpr bool FB = decltype(fb_t)::value, PB = decltype(pb_t)::value;
                     const unsigned long long inmask = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
                     const unsigned long long ovm_all = __ballot(in && ovg) & inmask;
-                    unsigned long long cmask = inmask, accm = 0ull;
+                    unsigned long long cmask = inmask, accm = 0ull, leftover = 0ull;
                     // The current state's chi²·Q enters a comparison as the pair (Na, Da), X = Sa - Na / Da, with (S - X, 1) at the
                     // head of a sub-window — "chi²_t < chi²" (mcsas.py:379), num² / den > Na / Da + (S - Sa), is taken across:
                     // num² Da > (Na + (S - Sa) Da) den.  With (S - X, 1) that is the very expression num² > (S - X) den; behind an
@@ -1674,6 +1675,10 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     // for every candidate unless positiveBackground can switch a candidate to the uncentred sums.
                     double Sa = PB ? X : 0., Na = PB ? 0. : (FB ? cScen : cSII) - X, Da = 1.0;
                     MCSAS_IN_VGPR(Na); MCSAS_IN_VGPR(Da);
+                    // Round 5: ONE exit (no candidate passes) and nothing in a round but the dependent chain itself — the step and
+                    // overflow counts are taken from the masks behind the loop, the accepted candidate's own convergence test is made
+                    // on its two numbers; a chain that ends inside the sub-window empties the candidate mask instead of leaving the
+                    // loop (one more, empty, round at the very end of an attempt).  The loop went from ~125 to ~60 instructions a round.
                     for (;;) {
                         const double SCt = SC + sc0, SICt = SIC + sc1, SCCt = SCC + fma(2., h, sc2);
                         double S = cSII, num = SICt, den = SCCt;
@@ -1687,38 +1692,35 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                             }
                         }
                         const double n2 = num * num;
-                        bool pass, conv;
+                        bool pass;
                         if constexpr (PB) {
                             pass = n2 * Da > fma(S - Sa, Da, Na) * den;
                         } else {
                             pass = n2 * Da > Na * den;
                         }
-                        conv = !((S - cCrit * cnq) * den > n2);      // this candidate, accepted, ends the attempt: !(chi² > criterion)
                         unsigned long long amask = __ballot(pass) & cmask;
-                        const unsigned long long convm = __ballot(conv);
                         if (never_accept) amask = 0ull;            // diagnostic: never accept
-                        if (amask == 0ull) {
-                            if (ovm_all & cmask) overflow = 1;
-                            num_iter += __builtin_popcountll(cmask);
-                            break;
-                        }
+                        if (amask == 0ull) break;
                         const int ga = __builtin_ctzll(amask);
                         const unsigned long long upto = (2ull << ga) - 1ull;          // steps 0 .. ga
                         // the steps behind the accepted one see ft + d_acc: h_k += Σ w d_acc d_k (read issued first)
                         const double gk = Gs[(size_t)ga * W + (in ? g : 0)];
-                        if (ovm_all & cmask & upto) overflow = 1;
                         SC = readlane_f64(SCt, ga); SIC = readlane_f64(SICt, ga); SCC = readlane_f64(SCCt, ga);
                         Na = readlane_f64(n2, ga); Da = readlane_f64(den, ga);
-                        // (the five stay where v_readlane put them — scalar registers — and enter the next round's
-                        // additions and products as scalar operands: ten moves per round less than pinned in VGPRs, -0.4 %)
-                        if constexpr (PB) { Sa = readlane_f64(S, ga); MCSAS_IN_VGPR(Sa); }
+                        double Sg = FB ? cScen : cSII;
+                        if constexpr (PB) { Sa = readlane_f64(S, ga); MCSAS_IN_VGPR(Sa); Sg = Sa; }
                         h += gk;
                         accm |= 1ull << ga;
-                        num_iter += __builtin_popcountll(cmask & upto);
                         cmask &= ~upto;
-                        ++num_moves;
-                        if ((convm >> ga) & 1ull) { live = false; break; }
-                        if (cmask == 0ull) break;
+                        // this candidate, accepted, ends the attempt: !(chi² > criterion), on its own (num², den)
+                        // (the ballot tells the compiler that the test — the same in every lane — is wave-uniform: masks stay scalar)
+                        if (__ballot(!((Sg - cCrit * cnq) * Da > Na)) != 0ull) { live = false; leftover = cmask; cmask = 0ull; }
+                    }
+                    {
+                        const unsigned long long consumed = inmask & ~leftover;       // the steps this sub-window went through
+                        num_iter += __builtin_popcountll(consumed);
+                        num_moves += __builtin_popcountll(accm);
+                        if (ovm_all & consumed) overflow = 1;
                     }
                     // the accepted steps of the sub-window, in order: sacc[1 + i] = step in the sub-window, lacc[...] = step in the window
                     nacc_sub = __builtin_popcountll(accm);

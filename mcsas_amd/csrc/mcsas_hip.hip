@@ -1085,7 +1085,11 @@ extern "C" int mcsas_hip_plan_create(const mcsas_problem *p, mcsas_plan **out) {
         if (rcg) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "workgroup kernel: needs 2*window <= n_contrib and the window in LDS (nq=%d, n_contrib=%d, waves=%d)", p->nq, (int)N, waves); }
         cache_rows = (int)N + 2 * pl->wg.window;
     } else if (mode == MCSAS_EXEC_PIPELINE) {
-        if (pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pl->pipe.g, model_traits(p->model_id).contrib_doubles)) { mcsas_hip_plan_destroy(pl); return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 (nq=%d, n_contrib=%d)", p->nq, (int)N); }
+        if (const int rcg = pipe_geometry(p->nq, (int)N, TABD(PIPE_BLOCK / 64), heavy_rows, rpw_req, sub_req, gram_global_req, eager_req, p->n_reps, n_cus, &pl->pipe.g, model_traits(p->model_id).contrib_doubles)) {
+            mcsas_hip_plan_destroy(pl);
+            if (rcg == 2) return fail(MCSAS_EINVAL, "pipeline: the window's row buffers / proposal records do not fit the 160 KB of LDS (nq=%d, n_contrib=%d)", p->nq, (int)N);
+            return fail(MCSAS_EINVAL, "pipeline: needs n_contrib >= 16 and nq <= 1024 (nq=%d, n_contrib=%d)", p->nq, (int)N);
+        }
         cache_rows = (int)N + 2 * pl->pipe.g.kb;
     }
     // The chains' row blocks must not all start at the same offset modulo the memory system's interleave: with N = 400 rows of

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 import mcsas_amd
 from mcsas_amd import engine
+from mcsas_amd import _lib
 from oracle import mcsas_oracle as O
 from helpers import load, make_models, traj_setup, FakeData, SMEAR_CASES, product_smearing, oracle_smearing, traj_smearing
 
@@ -1197,6 +1198,25 @@ def test_auto_mode_for_rows_with_an_integral():
             import torch
             assert torch.cuda.get_device_properties(0).multi_processor_count != 256, (ncontrib, reps, plan.info)   # (thresholds scale with the CU count)
         plan.close()
+
+
+def test_auto_mode_never_picks_a_mode_whose_working_set_does_not_fit():
+    """MCSAS_EXEC_AUTO: 9000 chains of config 4's shape (1000 contributions x 1024 q) would need 147 GB of row
+    cache plus window buffers in pipeline mode — more than half of the free memory — so AUTO runs them one wavefront per chain
+    without a cache, the way it did before the row queue; the pipeline asked for BY NAME is still refused with MCSAS_ENOMEM."""
+    import torch
+    if torch.cuda.mem_get_info(0)[0] > 290e9:
+        pytest.skip("device with more memory than the case is sized for")
+    q, I, sig = _synthetic(1024)
+    m, _ = make_models("ellcs", [1e-9, 2e-9, 2e-10], [1e-7, 2e-7, 1e-8])
+    st = engine.Settings(n_contrib=1000, n_reps=9000, max_iter=10, conv_crit=0.0, max_retries=0, seed=1)
+    plan = engine.Plan(m.setup(), q, I, sig, st)
+    assert plan.info["exec_mode"] == "wave" and not plan.info["cached_rows"], plan.info
+    plan.close()
+    with pytest.raises(_lib.McSASHipError) as e:
+        engine.Plan(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "exec_mode": engine.EXEC_PIPELINE}))
+    assert e.value.code == -4                                   # MCSAS_ENOMEM
+    engine.release_cached_memory()
 
 
 def test_uncertainty_floor_special_values():
