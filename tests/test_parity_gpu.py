@@ -98,7 +98,10 @@ TRAJ = ["g4_sphere_q100_fixed.npz", "g4_sphere_q100_converge.npz", "g4_sphere_q5
         "g17_cyl_q100_converge.npz", "g17_ellcs_q100_converge.npz", "g17_sphere_q100_posbg_converge.npz",
         # round 4: radially isotropic cylinders — no built-in kernel, the shipped model class hands its form factor to the library
         # as HIP text (mcsas_amd.CylindersRadiallyIsotropic.hipSource, rows with an integral): every mode compiled at run time
-        "g18_cylradiso_q40.npz"]
+        "g18_cylradiso_q40.npz",
+        # round 5: config 5 AS NAMED over 1300 steps = more than two sweeps over its 600 contributions (every contribution is proposed
+        # again after it may have been replaced: the eager slot swap of an accepted row is read back at the named shape)
+        "g9_kho_q512_long.npz"]
 
 
 @pytest.mark.parametrize("name", TRAJ)
@@ -312,12 +315,14 @@ def _heavy_free_setup(tag):
     return g, m, spec
 
 
-@pytest.mark.parametrize("tag,reps", [("cyl", 24), ("ellcs", 24), ("kho", 12)])
+@pytest.mark.parametrize("tag,reps", [("cyl", 24), ("ellcs", 24), ("kho", 12), ("kho32", 24)])
 def test_heavy_models_free_running_vs_the_reference_calc(tag, reps):
     """McSAS.calc() end to end and free-running for the models with an orientation / contour integral (mcsas.py:191-285 +
     :445-615), against the reference's own free run of the same workload (fixtures g16_*, oracle/make_golden.py
     gen_free_running_heavy: cylinders and core-shell ellipsoids 100 q x 200 contributions x 8 repetitions to criterion 1 on curves
-    of their own model, the worm-like chain on testdata/sasfit_kho-1-10-1000.dat 64 bins x 64 contributions x 3 repetitions):
+    of their own model, the worm-like chain on testdata/sasfit_kho-1-10-1000.dat 64 bins x 64 contributions x 3 repetitions to
+    criterion 12 ("kho", round 4: three reference repetitions, loose thresholds) and 32 bins x 48 contributions x 12 repetitions to
+    criterion 8 ("kho32", round 5: at the cylinders' thresholds)):
     every repetition here reaches the criterion, the mean number of iterations is the reference's within a factor, and every
     configured histogram (one per active parameter) agrees bin by bin within the two runs' standard errors; total volume fraction
     and the distribution mean (Moments.fields[0], [2]) within a few per cent."""
@@ -356,10 +361,11 @@ def test_heavy_models_free_running_vs_the_reference_calc(tag, reps):
         assert np.abs(z).max() < 5.0 and np.sqrt(np.mean(z**2)) < 2.0, (pre, z)
         mo = np.asarray(h.moments.fields, dtype=float)
         np.testing.assert_allclose(mo[[0, 2]], g[pre + "moments"][[0, 2]], rtol=0.05 if tag != "kho" else 0.25)
-    # the mean fitted curve: 5 % plus three standard errors of the two means (in the form-factor minima of the worm-like chain
-    # the reference's own three repetitions spread by 19 %, and its fit sits four sigma off the data there)
+    # the mean fitted curve within 5 %; the three-repetition worm fixture ("kho") alone gets three standard errors of the two means
+    # on top (in the form-factor minima the reference's own three repetitions spread by 19 %, and its fit sits four sigma off the data)
     fit_se = np.sqrt(np.asarray(res["fitMeasValStd"])**2 / reps + g["fitStd"]**2 / ref_reps)
-    assert (np.abs(res["fitMeasValMean"] - g["fitMean"]) <= 0.05 * np.abs(g["fitMean"]) + 3. * fit_se).all()
+    allow = 3. * fit_se if tag == "kho" else 0.
+    assert (np.abs(res["fitMeasValMean"] - g["fitMean"]) <= 0.05 * np.abs(g["fitMean"]) + allow).all()
 
 
 @pytest.mark.parametrize("mode", [engine.EXEC_PIPELINE, engine.EXEC_WAVE, engine.EXEC_WORKGROUP])

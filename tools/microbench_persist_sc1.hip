@@ -182,18 +182,55 @@ __global__ __launch_bounds__(T) void persist_sc1_kernel(const Args a, int t0, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------- (d) uncached buffers, plain accesses
+// The question behind it: could the product's tick kernels run several ticks per launch WITHOUT touching their memory accesses, only
+// by putting the buffers the workgroups exchange into memory the caches do not keep (hipDeviceMallocUncached, MTYPE UC)?  Plain
+// loads / stores, every storing wave drains, barrier, one lane signals (sc1 flag / agent atomic); the waiting side polls, barrier.
+// NOT one of MI355X_MICROARCH.md's validated forms: this variant is here to be CHECKED (every value) and timed, nothing else.
+__global__ __launch_bounds__(T) void persist_uc_kernel(const Args a, int t0, int nt) {
+    extern __shared__ double lds[];
+    const int b = blockIdx.x, r = b / (1 + a.G), role = b % (1 + a.G), tid = threadIdx.x;
+    for (int t = t0; t < t0 + nt; ++t) {
+        int err;
+        if (role == 0) {
+            if (t > t0) { if (!wait_sc1(a.prod_cnt + (r * 2 + (t & 1)) * 32, a.G * ((t - t0 + 1) / 2), a.abort_flag)) return; }
+            err = consume<0>(a, r, t, lds);
+            if (tid == 0) a.word[r * 32] = t + 1000 * r;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.scan_done + r * 32, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (t > t0) { if (!wait_sc1(a.scan_done + r * 32, t, a.abort_flag)) return; }
+            err = produce<0>(a, r, role - 1, t, lds);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(a.prod_cnt + (r * 2 + ((t + 1) & 1)) * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (err) atomicAdd(a.errors, 1);
+    }
+}
+
 int main(int argc, char **argv) {
     const int R = argc > 1 ? atoi(argv[1]) : 50, G = argc > 2 ? atoi(argv[2]) : 4, NT = argc > 3 ? atoi(argv[3]) : 200;
+    const bool uncached = argc > 4 && atoi(argv[4]) != 0;      // argv[4] = 1: payload and word in hipDeviceMallocUncached memory, variant (d) instead of (b)
     Args a{};
     a.R = R; a.G = G;
-    CHK(hipMalloc((void **)&a.buf, sizeof(double) * R * 2 * G * T * PER));
-    CHK(hipMalloc((void **)&a.word, 128 * R)); CHK(hipMalloc((void **)&a.scan_done, 128 * R)); CHK(hipMalloc((void **)&a.prod_cnt, 256 * R));
+    if (uncached) {
+        CHK(hipExtMallocWithFlags((void **)&a.buf, sizeof(double) * R * 2 * G * T * PER, hipDeviceMallocUncached));
+        CHK(hipExtMallocWithFlags((void **)&a.word, 128 * R, hipDeviceMallocUncached));
+        printf("payload buffers: hipDeviceMallocUncached; column (b) is variant (d): plain accesses, drained counter, NO fence\n");
+    } else {
+        CHK(hipMalloc((void **)&a.buf, sizeof(double) * R * 2 * G * T * PER));
+        CHK(hipMalloc((void **)&a.word, 128 * R));
+    }
+    CHK(hipMalloc((void **)&a.scan_done, 128 * R)); CHK(hipMalloc((void **)&a.prod_cnt, 256 * R));
     CHK(hipMalloc((void **)&a.errors, 4)); CHK(hipMalloc((void **)&a.abort_flag, 4));
     hipStream_t st; CHK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     const size_t lds = 147 * 1024;
     CHK(hipFuncSetAttribute((const void *)tick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CHK(hipFuncSetAttribute((const void *)persist_fence_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CHK(hipFuncSetAttribute((const void *)persist_uc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     constexpr int DEEP = PER == 24 ? 12 : 24, D0 = PER == 24 ? 6 : 8;
     CHK(hipFuncSetAttribute((const void *)persist_sc1_kernel<D0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CHK(hipFuncSetAttribute((const void *)persist_sc1_kernel<DEEP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -220,7 +257,8 @@ int main(int argc, char **argv) {
                     reset();
                     CHK(hipEventRecord(e0, st));
                     if (v == 0) for (int t = -1; t < NT; ++t) tick_kernel<<<R * (1 + G), T, lds, st>>>(a, t);
-                    if (v == 1) persist_fence_kernel<<<R * (1 + G), T, lds, st>>>(a, -1, NT + 1);
+                    if (v == 1 && !uncached) persist_fence_kernel<<<R * (1 + G), T, lds, st>>>(a, -1, NT + 1);
+                    if (v == 1 && uncached) persist_uc_kernel<<<R * (1 + G), T, lds, st>>>(a, -1, NT + 1);
                     if (v == 2) persist_sc1_kernel<D0, true><<<R * (1 + G), T, lds, st>>>(a, -1, NT + 1);
                     if (v == 3) persist_sc1_kernel<DEEP, true><<<R * (1 + G), T, lds, st>>>(a, -1, NT + 1);      // (c') deeper load queue
                     if (v == 4) persist_sc1_kernel<D0, false><<<R * (1 + G), T, lds, st>>>(a, -1, NT + 1);        // (c0) flags only: the consumer reads no payload
