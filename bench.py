@@ -581,10 +581,12 @@ def main():
                 out["roofline_valu"] = {"bound": "valu", "achieved": rate / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9,
                                         "unit": "G wave-instr/s", "frac": rate / FP64_VECTOR_PEAK_INSTR,
                                         "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"], "measured_in_this_run": False,
+                                        "profile_taken_on_these_kernel_sources": pv.get("csrc_sha16") == kernel_sources_sha16(),
                                         "source": "from_profile: %s (SQ_INSTS_VALU pass, commit %s)" % (ij, pv.get("commit", "?")),
                                         "note": "fp64 vector issue: 1024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz; achieved = "
                                                 "SQ_INSTS_VALU per MC step (committed counter pass) x MC steps per launch / mean HIP-event time of a launch"}
-            out["roofline"] = dict(algorithmic, traffic=traffic, traffic_unit="GB/s", traffic_source=source, traffic_measured_in_this_run=False)
+            out["roofline"] = dict(algorithmic, traffic=traffic, traffic_unit="GB/s", traffic_source=source, traffic_measured_in_this_run=False,
+                                   profile_taken_on_these_kernel_sources=bool(pm) and pm.get("csrc_sha16") == kernel_sources_sha16())
         # outside the timed region: the same repetitions run the way McSAS.analyse runs them — convergenceCriterion 1 (BASELINE),
         # maxIterations 1e5, one attempt — -> final chi² and how many got there, to be read against chisq_of_truth.
         if not dry and not args.no_convergence_run:
@@ -675,6 +677,18 @@ def named_totals(dev_index, world, rank, use_dist, backend, dry, barrier):
                          "reps_total": total, "reps_rank0": reps, "ranks_seen": ranks_seen, "n_gpus": world, "launches": launches,
                          "mc_steps": tot_steps, "timed_region_s": tmax, "exec_mode": info.get("exec_mode"), "window": info.get("window")}
     return out
+
+
+def kernel_sources_sha16():
+    """sha256 (16 hex digits) over the kernel sources (mcsas_amd/csrc/*.h, *.hip, in name order): tools/pmc_summary.py stores it beside
+    the per-step counters it derives, and the bench line says whether the counters it quotes were taken on THESE sources."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mcsas_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def latest_profile(suffix):
@@ -893,7 +907,7 @@ def many_chains(wl, dev_index, reps=8192, mc_steps=20000, seconds=1.5):
         r = pv["valu_wave_instr_per_mc_step"] * rate
         e["roofline"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
                          "frac": r / FP64_VECTOR_PEAK_INSTR, "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
-                         "measured_in_this_run": False,
+                         "measured_in_this_run": False, "profile_taken_on_these_kernel_sources": pv.get("csrc_sha16") == kernel_sources_sha16(),
                          "source": "from_profile: %s (SQ_INSTS_VALU pass, commit %s); rate measured in this run" % (ij, pv.get("commit", "?"))}
     return e
 
@@ -998,7 +1012,7 @@ def other_configs(dev_index, seconds=1.0):
             r = pv["valu_wave_instr_per_mc_step"] * rate_one
             e["roofline_valu"] = {"bound": "valu", "achieved": r / 1e9, "peak": FP64_VECTOR_PEAK_INSTR / 1e9, "unit": "G wave-instr/s",
                                   "frac": r / FP64_VECTOR_PEAK_INSTR, "instr_per_mc_step": pv["valu_wave_instr_per_mc_step"],
-                                  "measured_in_this_run": False,
+                                  "measured_in_this_run": False, "profile_taken_on_these_kernel_sources": pv.get("csrc_sha16") == kernel_sources_sha16(),
                                   "source": "from_profile: %s / %s (commit %s)" % (ij, tj, pv.get("commit", "?"))}
         out[str(cfg)] = e
     return out

@@ -250,3 +250,15 @@ def test_model_plugins_compile_without_a_gpu_and_report_compiler_errors():
         parameters = ()
     with pytest.raises(NotImplementedError):
         Nameless().setup()
+
+
+def test_committed_counter_profiles_describe_the_committed_kernels():
+    """bench.py quotes per-step counters (instructions, memory-side bytes) from the newest profiles/rNN_*.json; tools/pmc_summary.py
+    stores a hash of the kernel sources they were taken on, and the bench line reports whether it matches the tree.  Committed state:
+    it matches — a kernel change without a profile refresh fails here (and shows as `profile_taken_on_these_kernel_sources: false`)."""
+    import bench
+    for suffix in ("valu_per_step.json", "pmc_traffic.json"):
+        name, prof = bench.latest_profile(suffix)
+        assert name and prof, suffix
+        for key, entry in prof.items():
+            assert entry.get("csrc_sha16") == bench.kernel_sources_sha16(), (name, key)

@@ -136,6 +136,13 @@ def main():
         md += ["| %s | FETCH_SIZE | %d | %.0f | %.0f |" % (tag, nf, f.get("FETCH_SIZE", 0), fbytes),
                "| %s | WRITE_SIZE | %d | %.0f | %.0f |" % (tag, nw, w.get("WRITE_SIZE", 0), wbytes)]
     md += ["", "algorithmic figure of SURVEY 8d: 40 Q bytes per MC step = 20480 B at 512 q, 40960 B at 1024 q", ""]
+    # the kernel sources these counters describe (bench.py compares: a kernel change without a profile refresh shows in the bench line)
+    sys.path.insert(0, ROOT)
+    from bench import kernel_sources_sha16
+    sha = kernel_sources_sha16()
+    for d in (traffic, valu):
+        for v in d.values():
+            v["csrc_sha16"] = sha
     json.dump(traffic, open(os.path.join(OUT, ROUND + "_pmc_traffic.json"), "w"), indent=1)
     json.dump(valu, open(os.path.join(OUT, ROUND + "_valu_per_step.json"), "w"), indent=1)
     open(os.path.join(OUT, ROUND + "_summary.md"), "w").write("\n".join(md) + "\n")
