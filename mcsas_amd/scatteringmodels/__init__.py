@@ -401,6 +401,13 @@ def host_model_calc(model, data, pset, compensationExponent, want_rows=False):
     return cum, vset, wset, sset, (np.array(rows) if want_rows else None)
 
 
+def _as_float(v):
+    try:
+        return float(v)
+    except (TypeError, ValueError):
+        return 0.0
+
+
 def setup_from_model(model, data=None) -> engine.ModelSetup:
     """Flattens a configured model instance — ours or the reference's own (duck-typed through
     params()/name()/value()/isActive()/activeRange()/valueRange()/generator()) — into the
@@ -422,9 +429,11 @@ def setup_from_model(model, data=None) -> engine.ModelSetup:
         raise NotImplementedError("model %s has no HIP kernel (built in: %s), no `hipSource` text and no Python calcIntensity "
                                   "(formfactor + volume) either: see INTEGRATION.md" % (type(model).__name__, ", ".join(MODEL_IDS)))
     params = list(model.params())
-    if len(params) > engine.MAX_PARAMS:
+    if len(params) > engine.MAX_PARAMS and mid != engine.MODEL_HOST:
         raise NotImplementedError("model %s has %d parameters, the C ABI carries %d" % (type(model).__name__, len(params), engine.MAX_PARAMS))
-    values = np.array([float(p()) for p in params], dtype=float)
+    # (a model whose rows the host evaluates keeps its parameter vector to itself: only the ACTIVE parameters' generator ranges
+    # travel, so it may declare any number of parameters of any type)
+    values = np.array([_as_float(p()) for p in params[:engine.MAX_PARAMS]], dtype=float)
     active, lo, hi, kind, clo, chi, start = [], [], [], [], [], [], []
     for i, p in enumerate(params):
         if not isActiveFitParam(p):

@@ -549,6 +549,63 @@ def test_python_only_model_free_running_retries_and_stop():
         engine.analyse_host_rows(setup, q, I, sig, st2, bad)
 
 
+class PythonOnlyCoreShell(mcsas_amd.SASModel):
+    """models/sphericalcoreshell.py:14-77 typed as a user would: numpy only; eleven parameters (more than the C ABI's eight: a model
+    whose rows the host evaluates keeps its parameter vector to itself), two of them active."""
+    shortName = "Core-shell sphere (Python only)"
+    parameters = mcsas_amd.SphericalCoreShell.parameters + tuple(
+        (lambda n: (lambda: mcsas_amd.Parameter(n, 1.0, displayName="unused " + n)))("extra%d" % i) for i in range(6))
+
+    def __init__(self):
+        super().__init__()
+        self.radius.setActive(True); self.t.setActive(True)
+
+    def volume(self):
+        return 4. / 3 * np.pi * (self.radius() + self.t())**3
+
+    def formfactor(self, dataset):
+        q = self.getQ(dataset)
+
+        def k(rr, d_eta):
+            qr = q * rr
+            return d_eta * 3 * (np.sin(qr) - qr * np.cos(qr)) / (qr)**3
+        vc = 4. / 3 * np.pi * self.radius()**3
+        vt = 4. / 3 * np.pi * (self.radius() + self.t())**3
+        return k(self.radius() + self.t(), self.eta_s() - self.eta_sol()) - (vc / vt) * k(self.radius(), self.eta_s() - self.eta_c())
+
+
+def test_python_only_model_two_parameters_more_than_1024_q():
+    """Host rows with two active parameters (exponential generators), 1300 q-points (q slots beyond a wavefront's 1024) and a
+    model that declares more parameters than the C ABI carries: free-running chains follow the numpy oracle of the same model
+    (oracle: models/sphericalcoreshell.py restated) on the device's Philox streams, retries included."""
+    q = np.logspace(7, np.log10(3e9), 1300)
+    rs = np.random.RandomState(5)
+    m = PythonOnlyCoreShell()
+    lo, hi = [2e-9, 5e-10], [1e-7, 2e-8]
+    m.radius.setActiveRange((lo[0], hi[0])); m.t.setActiveRange((lo[1], hi[1]))
+    assert len(m.params()) == 11 and mcsas_amd.scatteringmodels.is_host_model(m)
+    _, spec = make_models("sphcs", lo, hi)
+    truth = np.stack([rs.uniform(5e-9, 5e-8, 30), rs.uniform(1e-9, 1e-8, 30)], axis=1)
+    It = O.model_calc(spec, q, truth, 0.6666666)[0]
+    It *= 1e3 / It.max()
+    sig = 0.02 * It
+    I = It * (1 + 0.02 * rs.normal(size=len(q)))
+    data = mcsas_amd.SASData(q, I, sig)
+    st = engine.Settings(n_contrib=40, n_reps=3, max_iter=150, conv_crit=1e-9, max_retries=1, seed=9)
+    rows = lambda pset: mcsas_amd.scatteringmodels.host_model_calc(m, data, pset, st.comp_exp, want_rows=True)[4]
+    res = engine.analyse_host_rows(m.setup(data), q, I, sig, st, rows, window=33)
+    ost = O.Settings(n_contrib=40, n_reps=1, max_iter=150, conv_crit=1e-9, max_retries=1)
+    for r in range(3):
+        stream = O.PhiloxStream(9, r)
+        for att in range(2):
+            ref = O.mc_fit(spec, q, I, sig, [I.min(), I.max()], [q.min(), q.max()], ost, stream, method="closed")
+        assert res.attempts[r] == 2 and res.num_iter[r] == ref.num_iter == 150 and res.num_moves[r] == ref.num_moves, r
+        assert res.draws[r] == stream.pos
+        np.testing.assert_allclose(res.contribs[:, :, r], ref.rset, rtol=1e-12)
+        np.testing.assert_allclose(res.chisq[r], ref.conval, rtol=1e-9)
+        np.testing.assert_allclose(res.fit[:, r], ref.fit, rtol=1e-9)
+
+
 @pytest.mark.parametrize("waves", [1, 8, 5, -3])
 def test_free_running_philox_matches_oracle(waves):
     """Free-running chains (device Philox) follow the oracle run with the same counter-based stream:
