@@ -217,6 +217,52 @@ def cpu_vs_gpu_chains(wl, steps, dev_index, seed=1):
             "compared": "%d chains, %d steps each, identical Philox streams (seed %d), GPU exec mode auto" % (threads, steps, seed)}
 
 
+def _numpy_rows(args):
+    """`n` Kholodenko rows at the workload's q grid through the numpy / QUADPACK restatement (one MC step of the reference = one such
+    row for the proposal, the `old` row being cached): seconds taken."""
+    q, lo, hi, n, seed = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import mcsas_oracle as O
+    spec = O.ModelSpec.make("kholodenko", ["radius", "lenKuhn", "lenContour"], lo, hi)
+    rs = np.random.RandomState(seed)
+    t0 = time.time()
+    for _ in range(n):
+        row = [O.transform(g, rs.rand()) * (h - l) + l for g, l, h in zip(spec.gen, spec.lo, spec.hi)]
+        O.calc_intensity(spec, q, row, 0.6666666)
+    return time.time() - t0
+
+
+def config5_cpu_and_reference(wl, dev_index, rows_per_proc=6):
+    """Config 5 has no C port (the reference integrates the worm's form factor with QUADPACK): (a) CPU baseline = the numpy / scipy
+    restatement's row rate, one process per core, a bounded sample (a step of the cached-row algorithm costs one row); (b) final
+    chi² against the REFERENCE ITSELF: tests/golden/g9_kho_q512_long.npz — the reference's own chain at this config's shape, 1300
+    steps — replayed here through the C ABI on the uniform stream the reference consumed."""
+    import multiprocessing as mp
+    from mcsas_amd import engine
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = max(1, min(avail, int(os.environ.get("MCSAS_BENCH_CPU_THREADS", "16"))))
+    setup = wl["model"].setup()
+    ctx = mp.get_context("spawn")
+    t0 = time.time()
+    with ctx.Pool(threads) as pool:
+        pool.map(_numpy_rows, [(wl["q"], list(setup.gen_lo), list(setup.gen_hi), rows_per_proc, 100 + c) for c in range(threads)])
+    dt = time.time() - t0
+    out = {"value": threads * rows_per_proc / dt, "unit": "MC steps/s", "cores": threads, "kind": "port",
+           "sample": "%d processes x %d form-factor rows of %d q (numpy / scipy QUADPACK restatement, oracle/mcsas_oracle.py; one row per "
+                     "MC step with cached `old` rows), %.1f s" % (threads, rows_per_proc, len(wl["q"]), dt)}
+    path = os.path.join(ROOT, "tests", "golden", "g9_kho_q512_long.npz")
+    if os.path.exists(path):
+        g = np.load(path)
+        st = engine.Settings(n_contrib=int(g["spec_n_contrib"]), n_reps=1, max_iter=int(g["spec_max_iter"]), conv_crit=float(g["spec_conv_crit"]),
+                             comp_exp=float(g["spec_comp_exp"]), max_retries=0, device=dev_index)
+        res = engine.analyse(setup, g["data_q"], g["data_I"], g["data_sigma"], st, replay=g["stream"][None, :])
+        out["chisq_rel_diff_vs_reference"] = abs(float(res.chisq[0]) - float(g["res_conval"])) / float(g["res_conval"])
+        out["moves_equal_reference"] = bool(int(res.num_moves[0]) == int(g["res_num_moves"]))
+        out["compared"] = "the reference's own chain (g9_kho_q512_long: 512 q x 600 contributions x %d steps, %d accepted) replayed on its uniform stream" % (
+            int(g["res_num_iter"]), int(g["res_num_moves"]))
+    return out
+
+
 def _numpy_chain(args):
     q, I, sigma, lo, hi, nsteps, chain = args
     os.environ["OMP_NUM_THREADS"] = "1"
@@ -616,10 +662,9 @@ def main():
                     e = cpu_vs_gpu_chains(workload(cfg, dev_index), steps_c, dev_index)
                     out["configs"][str(cfg)]["cpu_baseline"] = e
                     out["configs"][str(cfg)]["chisq_rel_diff_vs_cpu"] = e["chisq_rel_diff_vs_cpu"]
-                out["configs"]["5"]["cpu_baseline"] = None
-                out["configs"]["5"]["cpu_baseline_note"] = ("the C oracle restates the models of configs 2-4; the worm-like chain's checker is the "
-                                                            "numpy / QUADPACK restatement (1-2 rows per second): chain-by-chain parity of config 5 "
-                                                            "is tests/golden/g9_kho_q512*.npz, replayed by tests/test_parity_gpu.py")
+                e5 = config5_cpu_and_reference(workload(5, dev_index), dev_index)
+                out["configs"]["5"]["cpu_baseline"] = e5
+                out["configs"]["5"]["chisq_rel_diff_vs_reference"] = e5.get("chisq_rel_diff_vs_reference")
         print(json.dumps(out))
     if use_dist:
         tdist.destroy_process_group()
