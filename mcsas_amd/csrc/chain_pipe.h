@@ -183,8 +183,28 @@ static inline int pipe_geometry(int nq, int n_contrib, int tab_doubles, int heav
         if (const char *e = getenv("MCSAS_HIP_PIPE_KB_CAP")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= PIPE_BLOCK) cap = v; }   // (measurement knob, host only)
 #endif
         if (kb > cap) kb = cap;
+        // Few chains (round 5): a tick hands R x Kb rows to 8 waves per CU, and while that is only a few "rounds" of rows the
+        // tick lasts c0 + ceil(rounds) x (a row's time) — config 3's per-GPU share, 25 chains x 200 rows on 2048 wave slots, is 2.44
+        // rounds: a third round for a sixth of the rows; a window of 160 steps (1.95 rounds) runs 8.5 % faster (tools/kb_probe.py:
+        // 5.72 against 5.27e6 steps/s; the fixed part c0 of a tick — proposal records, scan blocks, the boundary — measured 0.7-0.95
+        // of a row's time, which is why halving the window to get ONE round loses: 13 worm chains, 296 -> 152 steps, -22 %).  Between two
+        // and four rounds the window is the multiple of 8 in [Kb/2, Kb] that maximises Kb / (0.75 + ceil(rounds)), the longest unless another
+        // is 2 % better; from four rounds on the queue evens the rounds out and the longest window wins (measured: configs 3 at 200
+        // chains, 4 at 50).  Nothing a chain decides depends on the window (PipeGeom::resum_every): same arrays, bit for bit.
+        if (n_chains > 0 && n_cus > 0) {
+            const double slots = 8.0 * (double)n_cus;
+            auto rate = [&](int c) { const double r = (double)n_chains * c / slots; return (double)c / (0.75 + (double)(long long)(r + 1.0 - 1e-9)); };
+            const double rmax = (double)n_chains * kb / slots;
+            if (rmax > 2.0 && rmax < 4.0) {                      // (a third or fourth round to shed; 2 -> 1 loses: 6 chains of config 4, 496 -> 336 steps, -10 %)
+                int best = kb;
+                double best_v = rate(kb);
+                for (int c = kb - 8; c >= 8 && 2 * c >= kb; c -= 8)
+                    if (rate(c) > best_v * 1.02) { best_v = rate(c); best = c; }
+                kb = best;
+            }
+        }
 #ifndef __HIPCC_RTC__
-        if (const char *e = getenv("MCSAS_HIP_PIPE_KB")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= kb) kb = v; }     // (measurement knob, host only)
+        if (const char *e = getenv("MCSAS_HIP_PIPE_KB")) { const int v = atoi(e) & ~7; if (v >= 8 && v <= ((n_contrib / 2) & ~7) && v <= cap) kb = v; }     // (measurement knob, host only)
 #endif
         if (kb < 8) return 1;
         // producer blocks per chain: enough to cover every CU by themselves — the launch then holds more workgroups than CUs, the

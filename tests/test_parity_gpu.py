@@ -1266,15 +1266,18 @@ def test_auto_mode_for_rows_with_an_integral():
 def test_auto_mode_never_picks_a_mode_whose_working_set_does_not_fit():
     """MCSAS_EXEC_AUTO: 9000 chains of config 4's shape (1000 contributions x 1024 q) would need 147 GB of row
     cache plus window buffers in pipeline mode — more than half of the free memory — so AUTO runs them one wavefront per chain
-    without a cache, the way it did before the row queue; the pipeline asked for BY NAME is still refused with MCSAS_ENOMEM."""
-    import torch
-    if torch.cuda.mem_get_info(0)[0] > 290e9:
-        pytest.skip("device with more memory than the case is sized for")
+    (which needs no window buffers and can do without its cache), the way it did before the row queue; the pipeline asked for BY NAME is still refused with MCSAS_ENOMEM."""
+    try:                                                        # (sized for the MI355X's 288 GB; torch is only asked, never needed)
+        import torch
+        if torch.cuda.mem_get_info(0)[0] > 290e9:
+            pytest.skip("device with more memory than the case is sized for")
+    except RuntimeError:
+        pass
     q, I, sig = _synthetic(1024)
     m, _ = make_models("ellcs", [1e-9, 2e-9, 2e-10], [1e-7, 2e-7, 1e-8])
     st = engine.Settings(n_contrib=1000, n_reps=9000, max_iter=10, conv_crit=0.0, max_retries=0, seed=1)
     plan = engine.Plan(m.setup(), q, I, sig, st)
-    assert plan.info["exec_mode"] == "wave" and not plan.info["cached_rows"], plan.info
+    assert plan.info["exec_mode"] == "wave", plan.info         # (its own 74 GB row cache is optional: kept when half the free memory holds it)
     plan.close()
     with pytest.raises(_lib.McSASHipError) as e:
         engine.Plan(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "exec_mode": engine.EXEC_PIPELINE}))
@@ -1677,8 +1680,10 @@ def test_rows_with_an_integral_give_the_same_chain_whatever_the_chain_count(tag)
     m, _ = make_models(tag, lo, hi, **kw)
     st = engine.Settings(n_contrib=400, n_reps=24, max_iter=900, conv_crit=1e-9, max_retries=0, seed=21, exec_mode=engine.EXEC_PIPELINE)
     one = engine.analyse(m.setup(), q, I, sig, st)
-    windows = {engine.Plan(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "n_reps": r})).info["window"] for r in (24, 12, 5)}
-    assert windows == {200}                                   # 2 Kb <= N = 400, a multiple of 8
+    windows = [engine.Plan(m.setup(), q, I, sig, engine.Settings(**{**st.__dict__, "n_reps": r})).info["window"] for r in (24, 12, 5)]
+    # 2 Kb <= N = 400, a multiple of 8 — and since round 5 the window follows the chain count where a tick is only a few rounds of rows
+    # (24 chains x 200 rows on 2048 wave slots are 2.3 rounds: 168 steps = 2 rounds; 12 and 5 chains: the longest): the arrays must not care
+    assert all(w % 8 == 0 and 100 <= w <= 200 for w in windows) and windows[2] == 200
     assert one.num_moves.min() > 0 and len(set(one.num_moves.tolist())) > 3
     again = engine.analyse(m.setup(), q, I, sig, st)
     for name in ("contribs", "fit", "chisq", "num_iter", "num_moves"):
