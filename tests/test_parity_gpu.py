@@ -549,6 +549,35 @@ def test_python_only_model_free_running_retries_and_stop():
         engine.analyse_host_rows(setup, q, I, sig, st2, bad)
 
 
+def test_python_only_model_flags_and_stream_end():
+    """Host rows with the settings that change mcFit's set-up and fit — startFromMinimum (mcsas.py:310-315: no draws for the initial
+    set), no background, positiveBackground — against the numpy oracle on the same replayed stream; and a replay stream that is too
+    short is reported (MCSAS_ESTREAM), as by every other entry point."""
+    g = load("g4_sphere_q100_fixed.npz")
+    q, I, sig = g["data_q"], g["data_I"], g["data_sigma"]
+    lo, hi = float(g["spec_lo"][0]), float(g["spec_hi"][0])
+    _, spec = make_models("sphere", [lo], [hi], sld=float(g["spec_sld"]))
+    stream = g["stream"][:60 + 300 + 4]
+    for flags in (dict(start_from_minimum=True), dict(find_background=False), dict(positive_background=True)):
+        m = PythonOnlySphere(); m.radius.setActiveRange((lo, hi)); m.sld.setValue(float(g["spec_sld"]))
+        data = mcsas_amd.SASData(q, I, sig, f_limit=g["data_f_limit"])
+        st = engine.Settings(n_contrib=60, n_reps=1, max_iter=300, conv_crit=1e-9, max_retries=0, **flags)
+        rows = lambda pset: mcsas_amd.scatteringmodels.host_model_calc(m, data, pset, st.comp_exp, want_rows=True)[4]
+        res = engine.analyse_host_rows(m.setup(data), q, I, sig, st, rows, replay=stream[None, :], window=64)
+        ost = O.Settings(n_contrib=60, n_reps=1, max_iter=300, conv_crit=1e-9, find_bg=st.find_background, pos_bg=st.positive_background,
+                         start_from_min=st.start_from_minimum)
+        ref = O.mc_fit(spec, q, I, sig, g["data_f_limit"], g["data_x0_limit"], ost, O.ReplayStream(stream), method="closed")
+        assert res.num_iter[0] == ref.num_iter == 300 and res.num_moves[0] == ref.num_moves, flags
+        assert res.draws[0] == (300 if st.start_from_minimum else 360)
+        np.testing.assert_allclose(res.contribs[:, :, 0], ref.rset, rtol=1e-13)
+        np.testing.assert_allclose(res.chisq[0], ref.conval, rtol=1e-9)
+        np.testing.assert_allclose([res.scaling[0], res.background[0]], [ref.scaling, ref.background], rtol=1e-8, atol=1e-300)
+    with pytest.raises(_lib.McSASHipError) as e:
+        engine.analyse_host_rows(m.setup(data), q, I, sig, engine.Settings(n_contrib=60, n_reps=1, max_iter=300, conv_crit=1e-9, max_retries=0),
+                                 rows, replay=stream[None, :200], window=64)
+    assert e.value.code == -5                                   # MCSAS_ESTREAM
+
+
 class PythonOnlyCoreShell(mcsas_amd.SASModel):
     """models/sphericalcoreshell.py:14-77 typed as a user would: numpy only; eleven parameters (more than the C ABI's eight: a model
     whose rows the host evaluates keeps its parameter vector to itself), two of them active."""
