@@ -1782,7 +1782,16 @@ __device__ __forceinline__ void pipe_scan_block(const PipeArgs &pa, double *lds,
                     const int i = tid + T * x;
                     if (i < qpad) {
                         double f = lft[i];
-                        for (int n = 0; n < nacc; ++n) f += rowbuf[(size_t)sacc[1 + n] * qpad + i];
+                        int n = 0;
+                        // (four rows at a time: their LDS reads are independent, the additions keep their order — early in a chain a
+                        // sub-window has a dozen accepted rows and a dependent read per row was a third of the tick's apply phase)
+                        for (; n + 4 <= nacc; n += 4) {
+                            const int r0 = sacc[1 + n], r1 = sacc[2 + n], r2 = sacc[3 + n], r3 = sacc[4 + n];
+                            const double v0 = rowbuf[(size_t)r0 * qpad + i], v1 = rowbuf[(size_t)r1 * qpad + i];
+                            const double v2 = rowbuf[(size_t)r2 * qpad + i], v3 = rowbuf[(size_t)r3 * qpad + i];
+                            f += v0; f += v1; f += v2; f += v3;
+                        }
+                        for (; n < nacc; ++n) f += rowbuf[(size_t)sacc[1 + n] * qpad + i];
                         lft[i] = f; lwft[i] = wq[x] * f;
                     }
                 }
