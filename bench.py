@@ -337,6 +337,8 @@ def main():
     ap.add_argument("--no-convergence-run", action="store_true",
                     help="skip the untimed run-to-convergence (profiling: only the timed launches reach the profiler)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of configs 3-5")
+    ap.add_argument("--totals-only", action="store_true", help="of configs 3-5 run only the named totals (200 / 400 / 100 repetitions sharded over the "
+                    "ranks), not the per-GPU-share runs a one-rank line carries beside them")
     ap.add_argument("--debug-flags", type=int, default=0, help="diagnostic role ablation (invalid results)")
     ap.add_argument("--streams", type=int, default=1, help="plans on streams of their own whose analyses overlap on the chip (default 1: "
                     "config 2 as named, one analysis on the chip at a time; the two-stream series figure is reported beside it)")
@@ -641,7 +643,7 @@ def main():
             out["calc_breakdown"] = calc_breakdown(wl, dev_index)
             out["quickstart"] = quickstart(dev_index)
             out["python_only_model"] = python_only_model(wl, dev_index)
-        if not dry and not args.no_configs and world == 1 and args.config == 2:
+        if not dry and not args.no_configs and not args.totals_only and world == 1 and args.config == 2:
             out["configs"] = other_configs(dev_index)
             for k, e in (totals or {}).items():                  # the named totals on ONE GPU: the denominator of a 1 -> N ratio
                 out["configs"][k]["strong_total"] = e
@@ -657,7 +659,7 @@ def main():
             cmp2 = cpu_vs_gpu_chains(wl, 20000, dev_index)
             out["cpu_baseline"].update({k: cmp2[k] for k in ("chisq_rel_diff_vs_cpu", "chisq_rel_diff_target", "moves_equal", "compared")})
             out["chisq_rel_diff_vs_cpu"] = cmp2["chisq_rel_diff_vs_cpu"]
-            if "configs" in out and not args.no_configs:
+            if "configs" in out and not args.no_configs and not args.totals_only:
                 for cfg, steps_c in ((3, 4000), (4, 3000)):
                     e = cpu_vs_gpu_chains(workload(cfg, dev_index), steps_c, dev_index)
                     out["configs"][str(cfg)]["cpu_baseline"] = e

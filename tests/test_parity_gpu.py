@@ -1962,3 +1962,24 @@ def test_bench_collective_path_runs_on_rccl(tmp_path):
     a = np.load(dump)
     assert a["contribs"].shape == (50, 400, 1) and a["fit"].shape == (50, 512) and np.isfinite(a["chisq"]).all()
     assert (a["chisq"] > 0).all() and (a["contribs"] > 0).all()
+
+
+def test_bench_named_totals_go_through_rccl(tmp_path):
+    """bench.py's named totals of configs 3-5 (200 / 400 / 100 repetitions sharded over the ranks: what `--gpus 8` reports per config)
+    with the process group on RCCL (one rank, MCSAS_BENCH_FORCE_DIST=1): every rank's block runs between barriers and the timings
+    meet in the MAX / SUM all-reduces on the device — executed on hardware here, at world size 1."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MCSAS_BENCH_FORCE_DIST="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MCSAS_BENCH_DRY", "MCSAS_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--launches-per-step", "2",
+           "--mc-steps", "2000", "--no-cpu-baseline", "--no-convergence-run", "--no-series", "--no-many-chains", "--totals-only"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["gather_ms"]["backend"] == "nccl"
+    for k, total in (("3", 200), ("4", 400), ("5", 100)):
+        c = line["configs"][k]
+        assert c["reps_total"] == c["reps_rank0"] == total and c["ranks_seen"] == 1 and c["scaling"] == "strong"
+        assert c["value"] > 1e6 and c["exec_mode"] == "pipeline" and c["mc_steps"] == 2 * total * {"3": 10000, "4": 15000, "5": 10000}[k]
