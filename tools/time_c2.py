@@ -16,8 +16,13 @@ plans = [engine.Plan(m.setup(), q, I, sig, st) for _ in range(K)]
 ms = [[] for _ in plans]
 for i in range(n + 8):
     for k, pl in enumerate(plans):
-        pl.reseed(1000 + i, 0); pl.launch(); res = pl.fetch(want_arrays=(i == 0))
-        if i == 0 and k == 0 and os.environ.get("TIME_DUMP"):
+        pl.reseed(1000 + i, 0); pl.launch()
+        try:
+            res = pl.fetch(want_arrays=(i == 0))
+        except mcsas_amd._lib.McSASHipError as e:             # (diagnostic builds whose chains do not finish: the launch time is still measured)
+            if i == 0 and k == 0: print("fetch:", e)
+            res = None
+        if i == 0 and k == 0 and os.environ.get("TIME_DUMP") and res is not None:
             np.savez(os.environ["TIME_DUMP"], contribs=res.contribs, chisq=res.chisq, moves=res.num_moves, iters=res.num_iter)
         if i >= 8:
             ms[k].append(pl.last_ms)
