@@ -11,7 +11,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 q, I, sig = synthetic_data(512)
 m = mcsas_amd.Sphere(); m.radius.setActiveRange((np.pi / q.max(), np.pi / q.min()))
-st = engine.Settings(n_contrib=400, n_reps=int(os.environ.get("TIME_REPS", "50")), max_iter=20000, conv_crit=0.0, max_retries=0, seed=20250101)
+st = engine.Settings(n_contrib=400, n_reps=int(os.environ.get("TIME_REPS", "50")), max_iter=20000, conv_crit=0.0, max_retries=0, seed=20250101,
+                     debug_flags=int(os.environ.get("MCSAS_DEBUG_FLAGS", "0")))   # (non-zero: the tuning build's ablation word)
 plans = [engine.Plan(m.setup(), q, I, sig, st) for _ in range(K)]
 ms = [[] for _ in plans]
 for i in range(n + 8):
@@ -26,5 +27,5 @@ for i in range(n + 8):
             np.savez(os.environ["TIME_DUMP"], contribs=res.contribs, chisq=res.chisq, moves=res.num_moves, iters=res.num_iter)
         if i >= 8:
             ms[k].append(pl.last_ms)
-print("env UNCACHED=%s TICKS_PER_LAUNCH=%s LIB=%s: plan medians %s ms; moves mean %s" % (os.environ.get("MCSAS_HIP_UNCACHED"), os.environ.get("MCSAS_HIP_TICKS_PER_LAUNCH"), os.path.basename(os.environ.get("MCSAS_HIP_LIB", "default")),
+print("env DEBUG_FLAGS=%s UNCACHED=%s TICKS_PER_LAUNCH=%s LIB=%s: plan medians %s ms; moves mean %s" % (os.environ.get("MCSAS_DEBUG_FLAGS"), os.environ.get("MCSAS_HIP_UNCACHED"), os.environ.get("MCSAS_HIP_TICKS_PER_LAUNCH"), os.path.basename(os.environ.get("MCSAS_HIP_LIB", "default")),
       " ".join("%.4f" % np.median(x) for x in ms), plans[0].info))
